@@ -1,0 +1,204 @@
+// C ABI: the reference's ratelib.h entry points (rate/rate_uni.c:27-111,210-231) plus the
+// device / batch extensions of include/ratelib_amd.h, all thin shims over rsmp::Engine.
+#include "../../include/ratelib_amd.h"
+
+#include "engine.hpp"
+
+#include <cstring>
+#include <new>
+#include <string>
+
+struct RR_handle_tag {
+  rsmp::Engine *eng;
+};
+
+namespace {
+
+void (*g_alloc_handler)(void) = nullptr;
+int g_initialized = 0;
+
+rsmp::Config to_config(const RR_config *c)
+{
+  rsmp::Config k;
+  k.in_rate = c->in_rate;
+  k.out_rate = c->out_rate;
+  k.phase = c->phase;
+  k.bandwidth = c->bandwidth;
+  k.allow_aliasing = c->allow_aliasing;
+  k.quality = c->quality == RR_best ? 0 : 1;
+  return k;
+}
+
+// engine codes are numerically the RR_error values; an allocation failure additionally runs the
+// registered handler (xmalloc.c:38-43) from this plain host frame, where unwinding is safe
+int finish(int rc)
+{
+  if (rc == RR_ENOMEM && g_alloc_handler) g_alloc_handler();
+  return rc;
+}
+
+int open_common(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle)
+{
+  if (handle == nullptr) return RR_INVPARAM;
+  *handle = nullptr;
+  if (!g_initialized) return RR_EXTUNINIT;
+  if (config == nullptr) return RR_INVPARAM;
+  RR_handle *h = new (std::nothrow) RR_handle_tag();
+  if (!h) return finish(RR_ENOMEM);
+  h->eng = nullptr;
+  int rc = rsmp::Engine::create(to_config(config), nchannels, nstreams, &h->eng);
+  if (rc != RR_OK) {
+    delete h;
+    return finish(rc);
+  }
+  *handle = h;
+  return RR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int init_ratelib(void (*alloc_error_handler)(void))
+{
+  g_initialized = 0;
+  if (alloc_error_handler == nullptr) return -1;
+  g_alloc_handler = alloc_error_handler;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return -1; // no GPU: refuse loudly, there is no CPU path
+  g_initialized = 1;
+  return 0;
+}
+
+void close_ratelib(void) { g_initialized = 0; }
+
+int RR_open(const RR_config *config, int nchannels, RR_handle **const handle) { return open_common(config, nchannels, 1, handle); }
+
+int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle)
+{
+  return open_common(config, nchannels, nstreams, handle);
+}
+
+int RR_push(RR_handle *h, const fb_sample_t *ibuf, size_t isamp)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->push_host(ibuf, isamp, isamp));
+}
+
+int RR_pull(RR_handle *h, fb_sample_t *obuf, size_t osamp, size_t *ogen)
+{
+  if (!h) return RR_NULLHANDLE;
+  size_t n = osamp < h->eng->available() ? osamp : h->eng->available();
+  return finish(h->eng->pull_host(obuf, n, osamp, ogen));
+}
+
+int RR_flow(RR_handle *h, const fb_sample_t *ibuf, fb_sample_t *obuf, size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
+{
+  if (!h) return RR_NULLHANDLE;
+  if (h->eng->nstreams() != 1) return RR_INVPARAM; // packed layout of a batch is ambiguous here
+  return finish(h->eng->flow_host(ibuf, isamp, obuf, osamp, isamp, osamp, iused, ogen));
+}
+
+int RR_drain(RR_handle *h)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->drain());
+}
+
+void RR_close(RR_handle **h)
+{
+  if (h == nullptr || *h == nullptr) return;
+  delete (*h)->eng;
+  delete *h;
+  *h = nullptr;
+}
+
+const char *RR_strerror(int error)
+{ // same strings as rate_uni.c:92-111
+  switch (error) {
+    case RR_OK: return "OK";
+    case RR_ENOMEM: return "Not enough memory";
+    case RR_INTERNAL: return "Internal error";
+    case RR_NULLHANDLE: return "NULL handle";
+    case RR_RATEERROR: return "Error in rate() functions";
+    case RR_EXTUNINIT: return "Externals not initialized";
+    default: return "Other error";
+  }
+}
+
+int RRX_push_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, size_t isamp)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->push_device(d_ibuf, in_stride, isamp));
+}
+
+int RRX_pull_device(RR_handle *h, fb_sample_t *d_obuf, size_t out_stride, size_t osamp, size_t *ogen)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->pull_device(d_obuf, out_stride, osamp, ogen));
+}
+
+int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, fb_sample_t *d_obuf, size_t out_stride,
+                    size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->flow_device(d_ibuf, in_stride, d_obuf, out_stride, isamp, osamp, iused, ogen));
+}
+
+int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->push_host(ibuf, in_stride, isamp));
+}
+
+int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->pull_host(obuf, out_stride, osamp, ogen));
+}
+
+int RRX_set_stream(RR_handle *h, void *hip_stream)
+{
+  if (!h) return RR_NULLHANDLE;
+  h->eng->set_stream(static_cast<hipStream_t>(hip_stream));
+  return RR_OK;
+}
+
+int RRX_sync(RR_handle *h)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->sync());
+}
+
+size_t RRX_isamp_max(const RR_handle *h) { return h ? h->eng->isamp_max() : 0; }
+size_t RRX_available(const RR_handle *h) { return h ? h->eng->available() : 0; }
+int RRX_channels(const RR_handle *h) { return h ? h->eng->nch() : 0; }
+int RRX_streams(const RR_handle *h) { return h ? h->eng->nstreams() : 0; }
+
+int RRX_describe_plan(const RR_config *config, char *buf, size_t cap)
+{
+  if (!config || !buf || !cap) return -RR_INVPARAM;
+  rsmp::ChainPlan plan;
+  int rc = rsmp::make_plan(to_config(config), plan);
+  if (rc) return -rc;
+  std::string s = plan.describe();
+  size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+  std::memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  return int(n);
+}
+
+int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, size_t *count)
+{
+  if (!config || which < 0 || which > 2) return RR_INVPARAM;
+  rsmp::ChainPlan plan;
+  int rc = rsmp::make_plan(to_config(config), plan);
+  if (rc) return rc;
+  const std::vector<double> &t = which == 2 ? plan.poly_table : plan.dft[which].taps;
+  if (count) *count = t.size();
+  if (out)
+    for (size_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
+  return RR_OK;
+}
+
+} // extern "C"

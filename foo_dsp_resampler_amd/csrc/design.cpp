@@ -1,0 +1,233 @@
+// Host-side filter design (fp64). See design.hpp.
+#include "design.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace rsmp {
+
+namespace {
+const double kPi = 3.14159265358979323846;
+
+unsigned bit_reverse(unsigned v, int bits)
+{
+  unsigned r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((v >> b) & 1u) << (bits - 1 - b);
+  return r;
+}
+} // namespace
+
+void fft_inplace(std::vector<cplx> &a, int sign)
+{
+  const size_t n = a.size();
+  int bits = 0;
+  while ((size_t(1) << bits) < n) ++bits;
+  for (size_t i = 0; i < n; ++i) {
+    size_t r = bit_reverse(unsigned(i), bits);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  std::vector<cplx> w(n / 2 ? n / 2 : 1);
+  for (size_t k = 0; k < n / 2; ++k) {
+    double th = 2 * kPi * double(k) / double(n);
+    w[k] = cplx(std::cos(th), sign * std::sin(th));
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len / 2, stride = n / len;
+    for (size_t base = 0; base < n; base += len)
+      for (size_t k = 0; k < half; ++k) {
+        cplx t = a[base + k + half] * w[k * stride];
+        cplx u = a[base + k];
+        a[base + k] = u + t;
+        a[base + k + half] = u - t;
+      }
+  }
+}
+
+double bessel_i0(double x)
+{
+  // power series, summed until it stops changing (effects_i_dsp.c:46-55)
+  double acc = 1, term = 1;
+  const double hx = x / 2;
+  for (int i = 1;; ++i) {
+    const double y = hx / i;
+    const double before = acc;
+    term *= y * y;
+    acc += term;
+    if (acc == before) break;
+  }
+  return acc;
+}
+
+int dft_block_length(int num_taps)
+{
+  int len = 8;
+  for (int n = num_taps; n > 2; n >>= 1) len <<= 1;
+  if (len < 65536) len *= 2;
+  return std::min(std::max(len, 2048), 131072);
+}
+
+double kaiser_beta(double att, double tr_bw)
+{
+  if (att >= 60) {
+    // cubic fits in `att`, one row per octave of transition width (effects_i_dsp.c:85-96)
+    static const double fit[10][4] = {
+        {-6.784957e-10, 1.02856e-05, 0.1087556, -0.8988365 + .001},
+        {-6.897885e-10, 1.027433e-05, 0.10876, -0.8994658 + .002},
+        {-1.000683e-09, 1.030092e-05, 0.1087677, -0.9007898 + .003},
+        {-3.654474e-10, 1.040631e-05, 0.1087085, -0.8977766 + .006},
+        {8.106988e-09, 6.983091e-06, 0.1091387, -0.9172048 + .015},
+        {9.519571e-09, 7.272678e-06, 0.1090068, -0.9140768 + .025},
+        {-5.626821e-09, 1.342186e-05, 0.1083999, -0.9065452 + .05},
+        {-9.965946e-08, 5.073548e-05, 0.1040967, -0.7672778 + .085},
+        {1.604808e-07, -5.856462e-05, 0.1185998, -1.34824 + .1},
+        {-1.511964e-07, 6.363034e-05, 0.1064627, -0.9876665 + .18},
+    };
+    const double octave = std::log(tr_bw / .0005) / std::log(2.);
+    const int lo = std::min(std::max(int(octave), 0), 9);
+    const int hi = std::min(std::max(1 + int(octave), 0), 9);
+    auto eval = [att](const double *c) { return ((c[0] * att + c[1]) * att + c[2]) * att + c[3]; };
+    const double b_lo = eval(fit[lo]), b_hi = eval(fit[hi]);
+    return b_lo + (b_hi - b_lo) * (octave - int(octave));
+  }
+  if (att > 50) return .1102 * (att - 8.7);
+  if (att > 20.96) return .58417 * std::pow(att - 20.96, .4) + .07886 * (att - 20.96);
+  return 0;
+}
+
+std::vector<double> design_lowpass(double Fp, double Fs, double Fn, double att, int &num_taps, int k, double beta)
+{
+  const bool estimate_len = num_taps == 0;
+  const int phases = std::max(k, 1), modulo = std::max(-k, 1);
+  const double rho = phases == 1 ? .5 : att < 120 ? .63 : .75;
+
+  const double fn = std::fabs(Fn);
+  Fp /= fn;
+  Fs /= fn;
+  double tr_bw = .5 * (Fs - Fp); // 6 dB point to stop-band edge
+  tr_bw /= phases;
+  Fs /= phases;
+  if (!(tr_bw <= .5 * Fs)) tr_bw = .5 * Fs;
+  const double Fc = Fs - tr_bw;
+
+  // lsx_kaiser_params (effects_i_dsp.c:129-135)
+  if (beta < 0) beta = kaiser_beta(att, tr_bw * .5 / Fc);
+  const double len_factor = att < 60 ? (att - 7.95) / (2.285 * kPi * 2)
+                                     : ((.0007528358 - 1.577737e-05 * beta) * beta + .6248022) * beta + .06186902;
+  if (estimate_len) {
+    num_taps = int(std::ceil(len_factor / tr_bw + 1));
+    if (phases > 1) {
+      int per_phase = num_taps / phases + 1;
+      per_phase = (per_phase + 3) & ~3;
+      num_taps = per_phase * phases - 1;
+    } else
+      num_taps = (num_taps + modulo - 2) / modulo * modulo + 1;
+  }
+  if (Fn < 0) return {};
+
+  // lsx_make_lpf (effects_i_dsp.c:110-127), scale = phases, no DC normalisation
+  std::vector<double> h(num_taps);
+  const int m = num_taps - 1;
+  const double gain = double(phases) / bessel_i0(beta), inv_half = 1 / (.5 * m + rho);
+  for (int i = 0; i <= m / 2; ++i) {
+    const double z = i - .5 * m, x = z * kPi, y = z * inv_half;
+    double v = x ? std::sin(Fc * x) / x : Fc;
+    v *= bessel_i0(beta * std::sqrt(1 - y * y)) * gain;
+    h[i] = v;
+    if (m - i != i) h[m - i] = v;
+  }
+  return h;
+}
+
+void to_phase(std::vector<double> &h, int &post_len, double phase)
+{
+  const double blend = (phase > 50 ? 100 - phase : phase) / 50; // 0: minimum phase ... 1: linear
+  int len = int(h.size());
+  int W = 32;
+  for (int i = len; i > 1; i >>= 1) W <<= 1;
+  const int half = W / 2;
+
+  std::vector<cplx> buf(W);
+  for (int i = 0; i < len; ++i) buf[i] = h[i];
+  fft_inplace(buf, +1);
+  buf[0] = cplx(buf[0].real(), 0); // the reference's packed real transform has no imaginary
+  buf[half] = cplx(buf[half].real(), 0); // part at DC / Nyquist
+
+  // count phase wraps and take the log magnitude, bins 0..W/2 (effects_i_dsp.c:206-224)
+  std::vector<double> wraps(half + 1), logmag(half + 1);
+  double prev2 = 0, cum2 = 0, prev1 = 0, cum1 = 0;
+  for (int k = 0; k <= half; ++k) {
+    const double re = buf[k].real(), im = buf[k].imag();
+    double angle = std::atan2(im, re);
+    double span = 2 * kPi, delta = angle - prev2;
+    double adj = span * ((delta < -span * .7) - (delta > span * .7));
+    prev2 = angle;
+    cum2 += adj;
+    angle += cum2;
+    span = kPi;
+    delta = angle - prev1;
+    adj = span * ((delta < -span * .7) - (delta > span * .7));
+    prev1 = angle;
+    cum1 += std::fabs(adj);
+    wraps[k] = cum1;
+    const double mag = std::sqrt(re * re + im * im);
+    logmag[k] = mag ? std::log(mag) : -26;
+  }
+
+  // real cepstrum, folded onto its causal half
+  for (int k = 0; k <= half; ++k) buf[k] = logmag[k];
+  for (int k = 1; k < half; ++k) buf[W - k] = logmag[k];
+  fft_inplace(buf, -1);
+  std::vector<double> cep(W);
+  for (int i = 0; i < W; ++i) cep[i] = buf[i].real() / W;
+  for (int i = 1; i < half; ++i) {
+    cep[i] *= 2;
+    cep[i + half] = 0;
+  }
+  for (int i = 0; i < W; ++i) buf[i] = cep[i];
+  fft_inplace(buf, +1); // real part: log magnitude, imaginary part: minimum phase
+
+  // blend the phase toward linear and rebuild the (Hermitian) spectrum (effects_i_dsp.c:236-246)
+  std::vector<cplx> spec(W);
+  spec[0] = std::exp(buf[0].real());
+  spec[half] = std::exp(buf[half].real());
+  for (int k = 1; k < half; ++k) {
+    const double ph = blend * (2.0 * k) / W * wraps[half] + (1 - blend) * (buf[k].imag() + wraps[k]) - wraps[k];
+    const double mag = std::exp(buf[k].real());
+    spec[k] = cplx(mag * std::cos(ph), mag * std::sin(ph));
+    spec[W - k] = std::conj(spec[k]);
+  }
+  fft_inplace(spec, -1);
+  std::vector<double> imp(W);
+  for (int i = 0; i < W; ++i) imp[i] = spec[i].real() / W;
+
+  // locate the impulse peak (effects_i_dsp.c:251-260)
+  int peak = 0;
+  double run = 0, best = 0;
+  const int search = int(wraps[half] / kPi + .5);
+  for (int i = 0; i <= search; ++i) {
+    run += imp[i];
+    if (std::fabs(run) > std::fabs(best)) {
+      best = run;
+      peak = i;
+    }
+  }
+  while (peak && std::fabs(imp[peak - 1]) > std::fabs(imp[peak]) && imp[peak - 1] * imp[peak] > 0) --peak;
+
+  int begin;
+  if (blend == 0)
+    begin = 0;
+  else if (blend == 1)
+    begin = peak - len / 2;
+  else {
+    begin = int((.997 - (2 - blend) * .22) * len + .5);
+    int end = int((.997 + (0 - blend) * .22) * len + .5);
+    begin = peak - (begin & ~3);
+    end = peak + 1 + ((end + 3) & ~3);
+    len = end - begin;
+  }
+  h.assign(len, 0.0);
+  for (int i = 0; i < len; ++i) h[i] = imp[(begin + (phase > 50 ? len - 1 - i : i) + W) & (W - 1)];
+  post_len = phase > 50 ? peak - begin : begin + len - (peak + 1);
+}
+
+} // namespace rsmp

@@ -1,0 +1,599 @@
+// Stream engine. See engine.hpp.
+#include "engine.hpp"
+
+#include "design.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace rsmp {
+
+namespace {
+
+bool pow2_ge2(int x) { return x >= 2 && !(x & (x - 1)); }
+int ilog2(long long v) { int l = 0; while ((1LL << l) < v) ++l; return l; }
+long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; return p; }
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return e_ == hipErrorOutOfMemory ? kNoMem : kInternal; \
+  } while (0)
+
+// host mirror of fft_device.hpp's schedule
+int first_radix(int log2m) { return (log2m & 3) ? (1 << (log2m & 3)) : 16; }
+int num_passes(int log2m) { return (log2m + 3) / 4; }
+
+} // namespace
+
+int Engine::create(const Config &cfg, int nch, int nstreams, Engine **out)
+{
+  if (!out) return kInvParam;
+  *out = nullptr;
+  if (nch < 1 || nstreams < 1) return kInvParam;
+  Engine *e = new (std::nothrow) Engine();
+  if (!e) return kNoMem;
+  int rc = e->init(cfg, nch, nstreams);
+  if (rc != kOk) {
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return kOk;
+}
+
+int Engine::upload(const void *src, size_t bytes, void **dst)
+{
+  HIP_TRY(hipMalloc(dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return kOk;
+}
+
+const double2 *Engine::twiddles(int log2m)
+{
+  if (d_tw_[log2m]) return d_tw_[log2m];
+  // [pass >= 1][r-1][k] = exp(+2 pi i r k / (16 Ns)); see fft_device.hpp
+  std::vector<double2> tab;
+  long long ns = first_radix(log2m);
+  for (int p = 1; p < num_passes(log2m); ++p, ns *= 16)
+    for (int r = 1; r < 16; ++r)
+      for (long long k = 0; k < ns; ++k) {
+        const long double th = 2.0L * 3.14159265358979323846264338327950288L * (long double)(r * k) / (long double)(16 * ns);
+        tab.push_back(make_double2((double)cosl(th), (double)sinl(th)));
+      }
+  if (tab.empty()) tab.push_back(make_double2(1, 0));
+  void *d = nullptr;
+  if (upload(tab.data(), tab.size() * sizeof(double2), &d) != kOk) return nullptr;
+  d_tw_[log2m] = static_cast<double2 *>(d);
+  return d_tw_[log2m];
+}
+
+int Engine::init(const Config &cfg, int nch, int nstreams)
+{
+  int rc = make_plan(cfg, plan_);
+  if (rc) return rc;
+  nch_ = nch;
+  S_ = nstreams;
+  C_ = nch * nstreams;
+
+  int dev_count = 0;
+  if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1) return kUninit; // no HIP device: fail loudly
+  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  own_stream_ = true;
+
+  const int ns = int(plan_.stages.size());
+  book_.wr.assign(ns + 1, 0);
+  book_.rd.assign(ns + 1, 0);
+  book_.st.assign(ns, Book::St());
+  rings_.assign(ns + 1, Ring());
+  for (int i = 0; i <= ns; ++i) rings_[i].f32 = (i == 0 || i == ns);
+
+  double bytes_per_in_frame = 0, rate = 1;
+  for (int i = 0; i < ns; ++i) {
+    const StageSpec &sp = plan_.stages[i];
+    book_.wr[i] = sp.preload; // rate_base.h:417-422
+    Book::St &st = book_.st[i];
+    if (sp.kind == StageKind::Dft) {
+      const DftFilter &f = plan_.dft[sp.filt];
+      const int log2n = ilog2(f.N);
+      const int log2p = pow2_ge2(sp.L) ? log2n - ilog2(sp.L) : log2n;
+      const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
+      if (!dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
+      st.remL = sp.remL0;
+      if (!d_G_[sp.filt]) { // G = DFT_N(L * h placed at (i + N - taps + 1) mod N) / N, rate_base.h:173-175
+        std::vector<cplx> g(f.N);
+        for (int i2 = 0; i2 < f.num_taps; ++i2) g[(i2 + f.N - f.num_taps + 1) & (f.N - 1)] = f.taps[i2] * sp.L;
+        fft_inplace(g, -1);
+        std::vector<double2> G(f.N);
+        for (int k = 0; k < f.N; ++k) G[k] = make_double2(g[k].real() / f.N, g[k].imag() / f.N);
+        void *d = nullptr;
+        if ((rc = upload(G.data(), G.size() * sizeof(double2), &d)) != kOk) return rc;
+        d_G_[sp.filt] = static_cast<double2 *>(d);
+      }
+      if (!twiddles(log2p) || !twiddles(log2nd)) return kNoMem;
+      double r = double(sp.L);
+      if (sp.step > 0) r /= sp.step; else r /= double(1 << -sp.step);
+      rate *= r;
+    } else if (sp.kind == StageKind::Poly) {
+      st.at = sp.order == 0 ? (sp.at0 >> 32) : sp.at0;
+      if (!d_poly_) {
+        void *d = nullptr;
+        if ((rc = upload(plan_.poly_table.data(), plan_.poly_table.size() * sizeof(double), &d)) != kOk) return rc;
+        d_poly_ = static_cast<double *>(d);
+      }
+      rate *= sp.out_in_ratio;
+    } else {
+      rate *= 0.5;
+    }
+    if (i + 1 < ns) bytes_per_in_frame += rate * 8.0 * C_;
+  }
+  // Keep the fp64 fifos between stages around the size of the Infinity Cache: a push is cut into
+  // time slabs, each slab runs through every stage before the next one starts.
+  const double budget = 192.0 * 1024 * 1024;
+  slab_frames_ = bytes_per_in_frame > 0 ? size_t(budget / bytes_per_in_frame) : plan_.isamp_max;
+  slab_frames_ = std::max<size_t>(slab_frames_, 8192);
+  slab_frames_ = std::min<size_t>(slab_frames_, std::max<size_t>(plan_.isamp_max, 1));
+  for (int i = 0; i <= ns; ++i)
+    if ((rc = ensure_ring(i, std::max<long long>(book_.wr[i], 1))) != kOk) return rc;
+  HIP_TRY(hipStreamSynchronize(stream_));
+  return kOk;
+}
+
+void Engine::free_garbage()
+{
+  for (void *p : garbage_) (void)hipFree(p);
+  garbage_.clear();
+}
+
+Engine::~Engine()
+{
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  free_garbage();
+  for (Ring &r : rings_) if (r.buf) (void)hipFree(r.buf);
+  for (double2 *&g : d_G_) if (g) (void)hipFree(g);
+  if (d_poly_) (void)hipFree(d_poly_);
+  for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
+  if (d_stage_) (void)hipFree(d_stage_);
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Engine::sync()
+{
+  HIP_TRY(hipStreamSynchronize(stream_));
+  free_garbage();
+  return kOk;
+}
+
+F32View Engine::f32_view(int f, const ExtIn *ein, const ExtOut *eout) const
+{
+  const Ring &r = rings_[f];
+  F32View v;
+  v.ring = static_cast<float *>(r.buf);
+  v.ring_mask = r.cap - 1;
+  v.ring_stream_stride = r.cap * nch_;
+  v.ext = nullptr;
+  v.ext_begin = v.ext_end = 0;
+  v.ext_stream_stride = 0;
+  v.nch = nch_;
+  if (ein && ein->ptr) {
+    v.ext = const_cast<float *>(ein->ptr);
+    v.ext_begin = ein->begin;
+    v.ext_end = ein->end;
+    v.ext_stream_stride = ein->stride_floats;
+  } else if (eout && eout->ptr) {
+    v.ext = eout->ptr;
+    v.ext_begin = eout->begin;
+    v.ext_end = eout->end;
+    v.ext_stream_stride = eout->stride_floats;
+  }
+  return v;
+}
+
+F64View Engine::f64_view(int f) const
+{
+  const Ring &r = rings_[f];
+  F64View v;
+  v.ring = static_cast<double *>(r.buf);
+  v.mask = r.cap - 1;
+  v.chan_stride = r.cap;
+  return v;
+}
+
+// Make ring f able to hold `live_needed` items/frames counted from book_.rd[f]; existing live data
+// [rd, wr) is carried over to the new ring at the same absolute indices.
+int Engine::ensure_ring(int f, long long live_needed)
+{
+  Ring &r = rings_[f];
+  if (r.buf && r.cap >= live_needed) return kOk;
+  const long long cap = next_pow2(std::max<long long>({live_needed, r.cap * 2, 4096}));
+  const size_t bytes = r.f32 ? size_t(cap) * nch_ * S_ * sizeof(float) : size_t(cap) * C_ * sizeof(double);
+  void *nb = nullptr;
+  HIP_TRY(hipMalloc(&nb, bytes));
+  HIP_TRY(hipMemsetAsync(nb, 0, bytes, stream_));
+  if (r.buf) {
+    Ring old = r;
+    r.buf = nb;
+    r.cap = cap;
+    const long long a0 = book_.rd[f], a1 = book_.wr[f];
+    F32View sf = {}, df = {};
+    F64View sd = {}, dd = {};
+    if (r.f32) {
+      df = f32_view(f, nullptr, nullptr);
+      sf = df;
+      sf.ring = static_cast<float *>(old.buf);
+      sf.ring_mask = old.cap - 1;
+      sf.ring_stream_stride = old.cap * nch_;
+    } else {
+      dd = f64_view(f);
+      sd = dd;
+      sd.ring = static_cast<double *>(old.buf);
+      sd.mask = old.cap - 1;
+      sd.chan_stride = old.cap;
+    }
+    HIP_TRY(launch_copy(r.f32, sf, sd, df, dd, a0, a1, C_, stream_));
+    garbage_.push_back(old.buf);
+  } else {
+    r.buf = nb;
+    r.cap = cap;
+  }
+  return kOk;
+}
+
+void Engine::note_input(Book &b, size_t n) const
+{ // rate_base.h:436-441
+  b.samples_in += n;
+  while (b.samples_in > plan_.cfg.in_rate && b.samples_out > plan_.cfg.out_rate) {
+    b.samples_in -= plan_.cfg.in_rate;
+    b.samples_out -= plan_.cfg.out_rate;
+  }
+}
+
+// One pass of rate_process (rate_base.h:425-432) after `n_new` frames were appended to fifo 0.
+// With launch == false only the counters move (used to size a drain).
+int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout)
+{
+  const int ns = int(plan_.stages.size());
+  note_input(b, n_new);
+  b.wr[0] += (long long)n_new;
+  F32View nof = {};
+  F64View nod = {};
+
+  for (int i = 0; i < ns; ++i) {
+    const StageSpec &sp = plan_.stages[i];
+    Book::St &st = b.st[i];
+    long long &rd = b.rd[i];
+    long long &wro = b.wr[i + 1];
+    const long long occ = b.wr[i] - rd;
+    const bool src_f32 = i == 0, dst_f32 = i + 1 == ns;
+    const long long rd_before = rd, wro_before = wro;
+    const long long out_offset = i + 1 < ns ? plan_.stages[i + 1].preload : 0;
+
+    // what the destination ring must be able to hold once this stage has run
+    auto dst_need = [&](long long wr_after) {
+      if (dst_f32 && eout.ptr) return std::max<long long>(0, wr_after - std::max(eout.end, b.rd[i + 1]));
+      return wr_after - b.rd[i + 1];
+    };
+
+    if (sp.kind == StageKind::Dft) {
+      const DftFilter &f = plan_.dft[sp.filt];
+      const int N = f.N, ov = f.num_taps - 1, V = N - ov, L = sp.L;
+      const bool stuffing = L != 1 && !pow2_ge2(L);
+      const int kept = sp.step < 0 ? N - ((((1 << -sp.step) - 1) * N + ov) >> -sp.step) : V; // dft_filter.h:187
+      long long num_in = std::max<long long>(0, occ);
+      const long long B0 = st.B;
+      int nblocks = 0;
+      while (st.remL + (long long)L * num_in >= N) { // dft_filter.h:78-84
+        const int span = V - st.remL + L - 1;
+        const int take = span / L, rem = span % L;
+        rd += take;
+        num_in -= take;
+        if (stuffing) st.remL = L - 1 - rem;
+        if (sp.step > 1) {
+          const int j = (V - st.remM + sp.step - 1) / sp.step; // dft_filter.h:150-152
+          st.remM = st.remM + j * sp.step - V;
+          wro += j;
+        } else
+          wro += kept;
+        ++nblocks;
+        ++st.B;
+      }
+      if (launch && nblocks) {
+        int rc = ensure_ring(i + 1, dst_need(wro));
+        if (rc) return rc;
+        const int log2n = ilog2(N);
+        DftArgs a;
+        a.G = d_G_[sp.filt];
+        const int log2p = pow2_ge2(L) ? log2n - ilog2(L) : log2n;
+        const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
+        a.tw_fwd = twiddles(log2p);
+        a.tw_inv = twiddles(log2nd);
+        a.B0 = B0;
+        a.out_offset = out_offset;
+        a.nblocks = nblocks;
+        a.C = C_;
+        a.L = L;
+        a.c0 = sp.remL0;
+        a.V = V;
+        a.Vout = kept;
+        a.q = (V - sp.remL0 + L - 1) / L;
+        a.M = sp.step > 1 ? sp.step : 1;
+        HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
+                           src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                           dst_f32 ? nod : f64_view(i + 1), a, stream_));
+      }
+    } else if (sp.kind == StageKind::Poly) {
+      const long long num_in = std::max<long long>(0, occ - sp.pre_post); // rate_base.h:130
+      long long count = 0, at_end = st.at;
+      const long long step = sp.order == 0 ? (sp.step64 >> 32) : sp.step64;
+      const long long lim = sp.order == 0 ? num_in * sp.L : (num_in << 32);
+      if (st.at < lim) count = (lim - st.at + step - 1) / step; // rate_filters_generic.h:281 / :477
+      at_end = st.at + count * step;
+      if (launch && count) {
+        int rc = ensure_ring(i + 1, dst_need(wro + count));
+        if (rc) return rc;
+        PolyArgs a;
+        a.tab = d_poly_;
+        a.rd = rd_before;
+        a.at = st.at;
+        a.step = step;
+        a.out_abs = wro_before;
+        a.count = count;
+        a.C = C_;
+        a.n = sp.n;
+        a.L = sp.L;
+        a.phase_bits = sp.phase_bits;
+        const double in_per_out = sp.order == 0 ? double(step) / sp.L : double(step) / 4294967296.0;
+        int tile = 2048;
+        while (tile > 256 && (tile * in_per_out + sp.n + 4) * 8 > 48 * 1024) tile >>= 1;
+        a.tile = tile;
+        a.win = int(tile * in_per_out) + sp.n + 4;
+        HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
+                            src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                            dst_f32 ? nod : f64_view(i + 1), a, stream_));
+      }
+      if (sp.order == 0) {
+        rd += at_end / sp.L; // rate_filters_generic.h:302-304
+        st.at = at_end % sp.L;
+      } else {
+        rd += at_end >> 32; // rate_filters_generic.h:499-500
+        st.at = at_end & 0xffffffffLL;
+      }
+      wro += count;
+    } else {
+      const long long avail = std::max<long long>(0, occ - sp.pre_post);
+      const long long num_out = (avail + 1) / 2; // rate_filters_generic.h:83
+      if (launch && num_out) {
+        int rc = ensure_ring(i + 1, dst_need(wro + num_out));
+        if (rc) return rc;
+        HalfArgs a;
+        a.rd = rd_before;
+        a.out_abs = wro_before;
+        a.count = num_out;
+        a.C = C_;
+        a.ncoef = sp.hb_n;
+        a.pre = sp.pre;
+        for (int k = 0; k < 13; ++k) a.coef[k] = k < sp.hb_n ? sp.hb[k] : 0.0;
+        HIP_TRY(launch_half(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                            dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_));
+      }
+      if (2 * num_out <= occ) rd += 2 * num_out; // fifo_read refuses to over-read, fifo.h:169
+      wro += num_out;
+    }
+  }
+  return kOk;
+}
+
+// Append `isamp` frames that live in device memory at d_in ([stream][frame][ch], `stride_frames`
+// between streams) and run the chain.  If d_out is given and the output fifo is empty, up to
+// out_cap produced frames are written straight into d_out (and counted as pulled).
+int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
+                 size_t *direct_out)
+{
+  if (direct_out) *direct_out = 0;
+  ExtIn ein;
+  ein.ptr = d_in;
+  ein.begin = book_.wr[0];
+  ein.end = ein.begin + (long long)isamp;
+  ein.stride_floats = (long long)stride_frames * nch_;
+  ExtOut eout;
+  const long long wr_out0 = book_.wr.back();
+  if (d_out && out_cap && book_.rd.back() == wr_out0) {
+    eout.ptr = d_out;
+    eout.begin = wr_out0;
+    eout.end = wr_out0 + (long long)out_cap;
+    eout.stride_floats = (long long)out_stride * nch_;
+  }
+  size_t done = 0;
+  while (done < isamp) {
+    const size_t n = std::min(slab_frames_, isamp - done);
+    int rc = advance(book_, n, true, ein, eout);
+    if (rc) return rc;
+    done += n;
+  }
+  // carry the part of this push that no stage has consumed yet into ring 0
+  const long long a0 = std::max(book_.rd[0], ein.begin), a1 = book_.wr[0];
+  if (a1 > a0) {
+    int rc = ensure_ring(0, book_.wr[0] - book_.rd[0]);
+    if (rc) return rc;
+    F32View src = f32_view(0, &ein, nullptr), dst = f32_view(0, nullptr, nullptr);
+    F64View nod = {};
+    HIP_TRY(launch_copy(true, src, nod, dst, nod, a0, a1, C_, stream_));
+  }
+  if (eout.ptr) {
+    const long long produced = book_.wr.back() - wr_out0;
+    const long long direct = std::min<long long>(produced, (long long)out_cap);
+    book_.rd.back() += direct;
+    book_.samples_out += size_t(direct);
+    if (direct_out) *direct_out = size_t(direct);
+  }
+  return kOk;
+}
+
+int Engine::push_device(const float *ibuf, size_t stream_stride, size_t isamp)
+{
+  if (!ibuf || !isamp) return kOk; // rate_base.h:623
+  if (isamp > plan_.isamp_max) isamp = plan_.isamp_max; // silently truncated, rate_base.h:624
+  return feed(ibuf, S_ > 1 ? stream_stride : isamp, isamp, nullptr, 0, 0, nullptr);
+}
+
+int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
+{
+  if (!ibuf || !isamp) return kOk;
+  if (isamp > plan_.isamp_max) isamp = plan_.isamp_max;
+  const size_t need = isamp * size_t(nch_) * size_t(S_);
+  if (need > stage_floats_) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (d_stage_) (void)hipFree(d_stage_);
+    d_stage_ = nullptr;
+    stage_floats_ = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_stage_), need * sizeof(float)));
+    stage_floats_ = need;
+  }
+  const size_t row = isamp * nch_ * sizeof(float);
+  if (S_ == 1) HIP_TRY(hipMemcpyAsync(d_stage_, ibuf, row, hipMemcpyHostToDevice, stream_));
+  else HIP_TRY(hipMemcpy2DAsync(d_stage_, row, ibuf, stream_stride * nch_ * sizeof(float), row, S_, hipMemcpyHostToDevice, stream_));
+  return feed(d_stage_, isamp, isamp, nullptr, 0, 0, nullptr);
+}
+
+// copy `frames` frames starting at the output read pointer to dst; does not move the pointer
+int Engine::copy_out(float *dst, size_t stride_frames, size_t frames, bool to_host)
+{
+  const int f = int(rings_.size()) - 1;
+  const Ring &r = rings_[f];
+  const long long rd = book_.rd[f];
+  if (to_host) {
+    size_t done = 0;
+    while (done < frames) { // at most two segments (ring wrap)
+      const long long pos = (rd + (long long)done) & (r.cap - 1);
+      const size_t n = std::min<size_t>(frames - done, size_t(r.cap - pos));
+      const size_t row = n * nch_ * sizeof(float);
+      const float *src = static_cast<const float *>(r.buf) + pos * nch_;
+      HIP_TRY(hipMemcpy2DAsync(dst + done * nch_, stride_frames * nch_ * sizeof(float), src, size_t(r.cap) * nch_ * sizeof(float),
+                               row, S_, hipMemcpyDeviceToHost, stream_));
+      done += n;
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+  } else {
+    ExtOut eo;
+    eo.ptr = dst;
+    eo.begin = rd;
+    eo.end = rd + (long long)frames;
+    eo.stride_floats = (long long)stride_frames * nch_;
+    F32View src = f32_view(f, nullptr, nullptr), dv = f32_view(f, nullptr, &eo);
+    F64View nod = {};
+    HIP_TRY(launch_copy(true, src, nod, dv, nod, rd, rd + (long long)frames, C_, stream_));
+  }
+  return kOk;
+}
+
+int Engine::pull_host(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen)
+{
+  if (!obuf || !osamp) { // rate_base.h:647
+    if (ogen) *ogen = 0;
+    return kOk;
+  }
+  const size_t n = std::min(osamp, available());
+  if (n) {
+    int rc = copy_out(obuf, S_ > 1 ? stream_stride : n, n, true);
+    if (rc) return rc;
+    book_.rd.back() += (long long)n;
+    book_.samples_out += n; // rate_base.h:448
+  }
+  if (ogen) *ogen = n;
+  return kOk;
+}
+
+int Engine::pull_device(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen)
+{
+  if (!obuf || !osamp) {
+    if (ogen) *ogen = 0;
+    return kOk;
+  }
+  const size_t n = std::min(osamp, available());
+  if (n) {
+    int rc = copy_out(obuf, S_ > 1 ? stream_stride : n, n, false);
+    if (rc) return rc;
+    book_.rd.back() += (long long)n;
+    book_.samples_out += n;
+  }
+  if (ogen) *ogen = n;
+  return kOk;
+}
+
+// rate_base.h:571-614: deliver what is ready, take the input, deliver again
+int Engine::flow_host(const float *ibuf, size_t in_stride, float *obuf, size_t out_stride, size_t isamp, size_t osamp,
+                      size_t *iused, size_t *ogen)
+{
+  size_t n1 = 0, n2 = 0;
+  if (!ibuf) isamp = 0;
+  if (isamp > plan_.isamp_max) isamp = plan_.isamp_max;
+  int rc = pull_host(obuf, out_stride, osamp, &n1);
+  if (rc) return rc;
+  if (isamp && (rc = push_host(ibuf, in_stride, isamp))) return rc;
+  if (n1 < osamp && obuf && (rc = pull_host(obuf + n1 * nch_, out_stride, osamp - n1, &n2))) return rc;
+  if (iused) *iused = isamp;
+  if (ogen) *ogen = n1 + n2;
+  return kOk;
+}
+
+int Engine::flow_device(const float *ibuf, size_t in_stride, float *obuf, size_t out_stride, size_t isamp, size_t osamp,
+                        size_t *iused, size_t *ogen)
+{
+  size_t n1 = 0, n2 = 0;
+  if (!ibuf) isamp = 0;
+  if (isamp > plan_.isamp_max) isamp = plan_.isamp_max;
+  if (S_ > 1 && obuf && out_stride < osamp) return kInvParam;
+  int rc = pull_device(obuf, out_stride, osamp, &n1);
+  if (rc) return rc;
+  if (isamp) {
+    // frames produced by this push land directly in the caller's buffer (no ring round trip)
+    float *direct = obuf && n1 < osamp ? obuf + n1 * nch_ : nullptr;
+    rc = feed(ibuf, S_ > 1 ? in_stride : isamp, isamp, direct, S_ > 1 ? out_stride : osamp, direct ? osamp - n1 : 0, &n2);
+    if (rc) return rc;
+    if (direct && !n2 && available() && n1 < osamp) { // the ring was not empty: fall back to a copy
+      size_t n3 = 0;
+      if ((rc = pull_device(direct, out_stride, osamp - n1, &n3))) return rc;
+      n2 = n3;
+    }
+  }
+  if (iused) *iused = isamp;
+  if (ogen) *ogen = n1 + n2;
+  return kOk;
+}
+
+// rate_base.h:454-468,662-672
+int Engine::drain()
+{
+  const size_t target = size_t(double(book_.samples_in) / plan_.factor + .5);
+  if (target <= book_.samples_out) return kOk;
+  const size_t remaining = target - book_.samples_out;
+  // how many 1024-frame blocks of silence the reference would feed: counters only
+  Book trial = book_;
+  size_t blocks = 0;
+  const ExtIn no_in;
+  const ExtOut no_out;
+  while (size_t(trial.wr.back() - trial.rd.back()) < remaining) {
+    int rc = advance(trial, 1024, false, no_in, no_out);
+    if (rc) return rc;
+    if (++blocks > (1u << 20)) return kInternal;
+  }
+  if (blocks) {
+    const size_t frames = blocks * 1024, floats = frames * size_t(nch_) * size_t(S_);
+    float *zeros = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&zeros), floats * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(zeros, 0, floats * sizeof(float), stream_));
+    // feed them one reference block at a time so that the counter wrap in rate_input sees the same sequence
+    for (size_t k = 0; k < blocks; ++k) {
+      int rc = feed(zeros + k * 1024 * nch_, frames, 1024, nullptr, 0, 0, nullptr);
+      if (rc) { garbage_.push_back(zeros); return rc; }
+    }
+    garbage_.push_back(zeros);
+  }
+  book_.wr.back() = book_.rd.back() + (long long)remaining; // fifo_trim_to
+  book_.samples_in = book_.samples_out = 0;
+  return kOk;
+}
+
+} // namespace rsmp

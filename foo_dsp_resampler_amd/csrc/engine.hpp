@@ -1,0 +1,99 @@
+// Stream engine: owns the device-resident fifos of one handle (S streams x nch channels, all
+// advancing in lock step), mirrors the reference's fifo/stage accounting on the host with integers
+// only (rate/rate_base.h:425-468, rate/dft_filter.h:78-84, rate/rate_filters_generic.h:275-304), and
+// turns every push into a short sequence of kernel launches on one HIP stream.
+//
+// No sample data is ever inspected on the host: how many frames each stage can produce after a push
+// is a pure function of the counters, so everything is enqueued asynchronously and the host only
+// synchronises when the caller needs bytes back (pull to host memory).
+#pragma once
+#include "kernels.hpp"
+#include "plan.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace rsmp {
+
+enum { kOk = 0, kNoMem = 1, kInternal = 2, kNullHandle = 3, kRateError = 4, kUninit = 5, kInvParam = 6 };
+
+// integer-only mirror of the reference's per-channel state (identical for every channel)
+struct Book {
+  std::vector<long long> wr, rd; // per fifo (num_stages + 1), absolute counts
+  struct St { long long B = 0; int remL = 0, remM = 0; long long at = 0; };
+  std::vector<St> st;
+  size_t samples_in = 0, samples_out = 0; // rate_base.h:226
+};
+
+class Engine {
+public:
+  static int create(const Config &cfg, int nch, int nstreams, Engine **out);
+  ~Engine();
+
+  const ChainPlan &plan() const { return plan_; }
+  int nch() const { return nch_; }
+  int nstreams() const { return S_; }
+  size_t isamp_max() const { return plan_.isamp_max; }
+  size_t available() const { return size_t(book_.wr.back() - book_.rd.back()); }
+
+  void set_stream(hipStream_t s) { stream_ = s; }
+  hipStream_t stream() const { return stream_; }
+  int sync();
+
+  // Host-memory API (RR_push / RR_pull / RR_flow semantics). Buffers: [stream][frame][channel] with
+  // `stream_stride` frames between streams (ignored when there is one stream).
+  int push_host(const float *ibuf, size_t stream_stride, size_t isamp);
+  int pull_host(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen);
+  int flow_host(const float *ibuf, size_t in_stride, float *obuf, size_t out_stride, size_t isamp, size_t osamp,
+                size_t *iused, size_t *ogen);
+  // Device-memory API: same semantics, pointers are HBM addresses, nothing is synchronised.
+  int push_device(const float *ibuf, size_t stream_stride, size_t isamp);
+  int pull_device(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen);
+  int flow_device(const float *ibuf, size_t in_stride, float *obuf, size_t out_stride, size_t isamp, size_t osamp,
+                  size_t *iused, size_t *ogen);
+  int drain();
+
+private:
+  Engine() = default;
+  int init(const Config &cfg, int nch, int nstreams);
+
+  struct Ring { // device ring of fifo f
+    void *buf = nullptr;
+    long long cap = 0; // items (f64) or frames (f32), power of two
+    bool f32 = false;
+  };
+  struct ExtIn { const float *ptr = nullptr; long long begin = 0, end = 0, stride_floats = 0; };
+  struct ExtOut { float *ptr = nullptr; long long begin = 0, end = 0, stride_floats = 0; };
+
+  int feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
+           size_t *direct_out);
+  int advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout);
+  int ensure_ring(int f, long long live_needed);
+  int copy_out(float *dst, size_t stride_frames, size_t frames, bool to_host);
+  F32View f32_view(int f, const ExtIn *ein, const ExtOut *eout) const;
+  F64View f64_view(int f) const;
+  void note_input(Book &b, size_t n) const;
+  int upload(const void *src, size_t bytes, void **dst);
+  const double2 *twiddles(int log2m);
+  void free_garbage();
+
+  ChainPlan plan_;
+  int nch_ = 0, S_ = 0, C_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false;
+  Book book_;
+  std::vector<Ring> rings_;
+  std::vector<void *> garbage_;
+  // device tables
+  double2 *d_G_[2] = {nullptr, nullptr};
+  double *d_poly_ = nullptr;
+  double2 *d_tw_[20] = {};
+  // staging for host pushes / drains
+  float *d_stage_ = nullptr;
+  size_t stage_floats_ = 0;
+  size_t slab_frames_ = 0;
+};
+
+} // namespace rsmp

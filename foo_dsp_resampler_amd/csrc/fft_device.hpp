@@ -1,0 +1,210 @@
+// Device-side fp64 complex FFT for one workgroup (gfx950).
+//
+// Layout: an M-point transform is held by T = M/16 threads, 16 points per thread, in registers:
+// thread `tid` owns x[tid + s*T], s = 0..15 ("slots"), both on entry and on exit (natural order,
+// no bit reversal: Stockham autosort).  Passes are radix-R0 (R0 = 2,4,8 or 16, twiddle-free) followed
+// by radix-16 passes; between passes the 16 register values are exchanged through LDS
+// (ds_write_b128 / ds_read_b128, or two 8-byte half exchanges in SPLIT mode so that a 16384-point
+// transform fits 128 KiB of LDS).  The last pass leaves its results in registers.
+//
+// Twiddles come from a per-size table in HBM/L2 laid out [pass][r-1][k] so that consecutive lanes read
+// consecutive 16-byte entries; entries are exp(+2 pi i r k / (Ns*16)), conjugated on the fly for DIR<0.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rsmp {
+
+struct c64 { double x, y; };
+
+__device__ __forceinline__ c64 cadd(c64 a, c64 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c64 csub(c64 a, c64 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c64 cmul(c64 a, c64 w) { return {fma(a.x, w.x, -a.y * w.y), fma(a.x, w.y, a.y * w.x)}; }
+__device__ __forceinline__ c64 cmulc(c64 a, c64 w) { return {fma(a.x, w.x, a.y * w.y), fma(a.y, w.x, -a.x * w.y)}; } // a*conj(w)
+// multiply by exp(DIR * i pi/2)
+template <int DIR> __device__ __forceinline__ c64 rot90(c64 a) { return DIR > 0 ? c64{-a.y, a.x} : c64{a.y, -a.x}; }
+// multiply by the unit-modulus constant (c + DIR*i*s)
+template <int DIR> __device__ __forceinline__ c64 crot(c64 a, double c, double s)
+{
+  return DIR > 0 ? c64{fma(a.x, c, -a.y * s), fma(a.y, c, a.x * s)} : c64{fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s)};
+}
+
+template <int DIR> __device__ __forceinline__ void bfly2(c64 &a, c64 &b)
+{
+  c64 t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+
+// in: natural order a0..a3, out: natural order X0..X3
+template <int DIR> __device__ __forceinline__ void bfly4(c64 &a0, c64 &a1, c64 &a2, c64 &a3)
+{
+  c64 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = rot90<DIR>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a2 = csub(t0, t2);
+  a1 = cadd(t1, t3);
+  a3 = csub(t1, t3);
+}
+
+template <int R, int DIR> struct Bfly;
+
+template <int DIR> struct Bfly<2, DIR> {
+  static __device__ __forceinline__ void run(c64 (&b)[2]) { bfly2<DIR>(b[0], b[1]); }
+};
+template <int DIR> struct Bfly<4, DIR> {
+  static __device__ __forceinline__ void run(c64 (&b)[4]) { bfly4<DIR>(b[0], b[1], b[2], b[3]); }
+};
+template <int DIR> struct Bfly<8, DIR> {
+  static __device__ __forceinline__ void run(c64 (&b)[8])
+  {
+    const double h = 0.70710678118654752440;
+    // even / odd 4-point transforms
+    bfly4<DIR>(b[0], b[2], b[4], b[6]);
+    bfly4<DIR>(b[1], b[3], b[5], b[7]);
+    c64 o1 = crot<DIR>(b[3], h, h);   // W8^1
+    c64 o2 = rot90<DIR>(b[5]);        // W8^2
+    c64 o3 = crot<DIR>(b[7], -h, h);  // W8^3
+    c64 e0 = b[0], e1 = b[2], e2 = b[4], e3 = b[6], o0 = b[1];
+    b[0] = cadd(e0, o0); b[4] = csub(e0, o0);
+    b[1] = cadd(e1, o1); b[5] = csub(e1, o1);
+    b[2] = cadd(e2, o2); b[6] = csub(e2, o2);
+    b[3] = cadd(e3, o3); b[7] = csub(e3, o3);
+  }
+};
+template <int DIR> struct Bfly<16, DIR> {
+  static __device__ __forceinline__ void run(c64 (&b)[16])
+  {
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173; // cos, sin(pi/8)
+    const double h = 0.70710678118654752440;
+    // step 1: for each n2, 4-point transform over n1 of x[4 n1 + n2]  -> A[n2][k1] stored at b[4 k1 + n2]
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) bfly4<DIR>(b[n2], b[4 + n2], b[8 + n2], b[12 + n2]);
+    // step 2: twiddle A[n2][k1] by W16^(n2 k1)
+    b[4 + 1] = crot<DIR>(b[4 + 1], c1, s1);   // k1=1,n2=1 : W^1
+    b[4 + 2] = crot<DIR>(b[4 + 2], h, h);     //        n2=2 : W^2
+    b[4 + 3] = crot<DIR>(b[4 + 3], s1, c1);   //        n2=3 : W^3
+    b[8 + 1] = crot<DIR>(b[8 + 1], h, h);     // k1=2,n2=1 : W^2
+    b[8 + 2] = rot90<DIR>(b[8 + 2]);          //        n2=2 : W^4
+    b[8 + 3] = crot<DIR>(b[8 + 3], -h, h);    //        n2=3 : W^6
+    b[12 + 1] = crot<DIR>(b[12 + 1], s1, c1);   // k1=3,n2=1 : W^3
+    b[12 + 2] = crot<DIR>(b[12 + 2], -h, h);    //        n2=2 : W^6
+    b[12 + 3] = crot<DIR>(b[12 + 3], -c1, -s1); //        n2=3 : W^9
+    // step 3: for each k1, 4-point transform over n2 -> X[k1 + 4 k2] lands at b[4 k1 + k2]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) bfly4<DIR>(b[4 * k1], b[4 * k1 + 1], b[4 * k1 + 2], b[4 * k1 + 3]);
+    // reorder b[4 k1 + k2] -> X[k1 + 4 k2]  (a 4x4 transpose of register names)
+    c64 t;
+    t = b[1]; b[1] = b[4]; b[4] = t;
+    t = b[2]; b[2] = b[8]; b[8] = t;
+    t = b[3]; b[3] = b[12]; b[12] = t;
+    t = b[6]; b[6] = b[9]; b[9] = t;
+    t = b[7]; b[7] = b[13]; b[13] = t;
+    t = b[11]; b[11] = b[14]; b[14] = t;
+  }
+};
+
+// first-pass radix for an M-point transform held as 16 points/thread
+constexpr int fft_first_radix(int log2m) { return (log2m & 3) ? (1 << (log2m & 3)) : 16; }
+constexpr int fft_num_passes(int log2m) { return (log2m + 3) / 4; }
+// number of twiddle entries (c64) of the table for size 2^log2m: sum over passes p>=1 of 15*Ns_p
+constexpr int fft_twiddle_count(int log2m)
+{
+  int n = 0, ns = fft_first_radix(log2m);
+  for (int p = 1; p < fft_num_passes(log2m); ++p) {
+    n += 15 * ns;
+    ns *= 16;
+  }
+  return n;
+}
+
+// Exchange the 16 register values through LDS: value in slot s goes to Stockham position pos[s];
+// afterwards slot s holds element tid + s*T.  All threads of the workgroup must call this
+// (barriers); only `active` threads move data.
+template <int T, bool SPLIT>
+__device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16], int tid, bool active, double *lds)
+{
+  if (!SPLIT) {
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) l2[pos[s]] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        double2 q = l2[tid + s * T];
+        v[s] = {q.x, q.y};
+      }
+    }
+    __syncthreads();
+  } else {
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) lds[pos[s]] = v[s].x;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) v[s].x = lds[tid + s * T];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) lds[pos[s]] = v[s].y;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) v[s].y = lds[tid + s * T];
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOG2M, int R, int NS, int DIR, bool SPLIT, bool LAST>
+__device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
+{
+  constexpr int T = (1 << LOG2M) / 16, NB = 16 / R;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      c64 b[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) b[r] = v[t + NB * r];
+      if (NS > 1) {
+        const int k = (tid + t * T) & (NS - 1);
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const double2 w = tw[(r - 1) * NS + k];
+          b[r] = DIR > 0 ? cmul(b[r], c64{w.x, w.y}) : cmulc(b[r], c64{w.x, w.y});
+        }
+      }
+      Bfly<R, DIR>::run(b);
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[t + NB * r] = b[r];
+    }
+  }
+  if (!LAST) {
+    int pos[16];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int j = tid + t * T, k = j & (NS - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) pos[t + NB * r] = (j - k) * R + k + r * NS;
+    }
+    lds_exchange<T, SPLIT>(v, pos, tid, active, lds);
+  }
+}
+
+// Full transform.  `tw` points at this size's table (fft_twiddle_count(LOG2M) entries).
+template <int LOG2M, int DIR, bool SPLIT>
+__device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
+{
+  constexpr int R0 = fft_first_radix(LOG2M), NP = fft_num_passes(LOG2M);
+  fft_pass<LOG2M, R0, 1, DIR, SPLIT, NP == 1>(v, tid, active, tw, lds);
+  if constexpr (NP >= 2) fft_pass<LOG2M, 16, R0, DIR, SPLIT, NP == 2>(v, tid, active, tw, lds);
+  if constexpr (NP >= 3) fft_pass<LOG2M, 16, R0 * 16, DIR, SPLIT, NP == 3>(v, tid, active, tw + 15 * R0, lds);
+  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, SPLIT, NP == 4>(v, tid, active, tw + 15 * R0 * 17, lds);
+}
+
+} // namespace rsmp

@@ -1,0 +1,399 @@
+// HIP kernels for the stage chain (gfx950 / MI355X).
+//
+//   dft_kernel  : overlap-save FFT-FIR stage (reference: rate/dft_filter.h:60-190), one workgroup per
+//                 (block, channel PAIR): the two channels ride as real / imaginary part of one complex
+//                 transform, so no real-FFT split pass is needed and stereo frames load as one complex.
+//   poly_kernel : polyphase FIR stage, orders 0..3 (reference: rate/rate_filters_generic.h:272-504).
+//   half_kernel : half-band decimate-by-2 (reference: rate/rate_filters_generic.h:80-249).
+//
+// All arithmetic is fp64 (the reference's "Best" path is `sox_sample_t = double`, rate/rate_base.h:63-67);
+// float32 only at the caller-facing ends, converted with round-to-nearest-even like the C cast in
+// rate/rate_base.h:559-563.
+#include "kernels.hpp"
+
+#include "fft_device.hpp"
+
+namespace rsmp {
+
+// ---------------------------------------------------------------------------------------------
+// fifo accessors (see kernels.hpp for the coordinate convention)
+// ---------------------------------------------------------------------------------------------
+struct AnyView {
+  int is_f32;
+  F32View f;
+  F64View d;
+};
+
+struct ChanRef { // per-channel precomputed addressing
+  int is_f32;
+  // f32
+  const float *ring32;
+  const float *ext32;
+  long long mask32, ext_begin, ext_end;
+  int nch;
+  // f64
+  const double *ring64;
+  long long mask64;
+};
+
+__device__ __forceinline__ ChanRef chan_ref(const AnyView &v, int c)
+{
+  ChanRef r;
+  r.is_f32 = v.is_f32;
+  if (v.is_f32) {
+    const int s = c / v.f.nch, ch = c - s * v.f.nch;
+    r.ring32 = v.f.ring + s * v.f.ring_stream_stride + ch;
+    r.ext32 = v.f.ext ? v.f.ext + s * v.f.ext_stream_stride + ch : nullptr;
+    r.mask32 = v.f.ring_mask;
+    r.ext_begin = v.f.ext_begin;
+    r.ext_end = v.f.ext_end;
+    r.nch = v.f.nch;
+    r.ring64 = nullptr;
+    r.mask64 = 0;
+  } else {
+    r.ring64 = v.d.ring + (long long)c * v.d.chan_stride;
+    r.mask64 = v.d.mask;
+    r.ring32 = r.ext32 = nullptr;
+    r.mask32 = r.ext_begin = r.ext_end = 0;
+    r.nch = 1;
+  }
+  return r;
+}
+
+__device__ __forceinline__ double fifo_get(const ChanRef &r, long long a)
+{
+  if (r.is_f32) {
+    if (r.ext32 && a >= r.ext_begin && a < r.ext_end) return (double)r.ext32[(a - r.ext_begin) * r.nch];
+    return (double)r.ring32[(a & r.mask32) * r.nch];
+  }
+  return r.ring64[a & r.mask64];
+}
+
+__device__ __forceinline__ void fifo_put(const ChanRef &r, long long a, double v)
+{
+  if (r.is_f32) {
+    if (r.ext32 && a >= r.ext_begin && a < r.ext_end) const_cast<float *>(r.ext32)[(a - r.ext_begin) * r.nch] = (float)v;
+    else const_cast<float *>(r.ring32)[(a & r.mask32) * r.nch] = (float)v;
+  } else
+    const_cast<double *>(r.ring64)[a & r.mask64] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DFT stage
+// ---------------------------------------------------------------------------------------------
+template <bool SPLIT> struct LdsCx {
+  double *p;
+  __device__ __forceinline__ void put(int idx, c64 v, int h) const
+  {
+    if (!SPLIT) reinterpret_cast<double2 *>(p)[idx] = make_double2(v.x, v.y);
+    else p[idx] = h ? v.y : v.x;
+  }
+  __device__ __forceinline__ void get(int idx, c64 &v, int h) const
+  {
+    if (!SPLIT) {
+      const double2 q = reinterpret_cast<const double2 *>(p)[idx];
+      v = {q.x, q.y};
+    } else if (h) v.y = p[idx];
+    else v.x = p[idx];
+  }
+};
+
+template <int LOG2N, int LOG2P, int LOG2ND>
+__global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyView out, DftArgs a)
+{
+  constexpr int N = 1 << LOG2N, P = 1 << LOG2P, ND = 1 << LOG2ND;
+  constexpr int T = N / 16, TF = P / 16, TD = ND / 16;
+  constexpr bool SPLIT = LOG2N >= 14;
+  constexpr int ROUNDS = SPLIT ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int tid = threadIdx.x;
+  const long long B = a.B0 + blockIdx.x;
+  const int ca = 2 * blockIdx.y, cb = ca + 1;
+  const bool hasb = cb < a.C;
+  const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+
+  c64 v[16];
+  const bool fwd_active = tid < TF;
+  if (fwd_active) {
+    if (LOG2P < LOG2N || a.L == 1) {
+      const long long base = B * a.q;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const long long e = base + tid + s * TF;
+        v[s].x = fifo_get(ia, e);
+        v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+      }
+    } else { // time-domain zero stuffing (dft_filter.h:109-115) in absolute coordinates
+      const long long U = B * a.V;
+      const long long j0 = (U - a.c0 + a.L - 1) / a.L;
+      const int remL = (int)(j0 * a.L + a.c0 - U);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int d = tid + s * TF - remL;
+        v[s] = {0.0, 0.0};
+        if (d >= 0 && d % a.L == 0) {
+          const long long e = j0 + d / a.L;
+          v[s].x = fifo_get(ia, e);
+          v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+        }
+      }
+    }
+  }
+
+  fft_regs<LOG2P, -1, SPLIT>(v, tid, fwd_active, a.tw_fwd, lds);
+
+  const LdsCx<SPLIT> L{lds};
+  if constexpr (LOG2P == LOG2N && LOG2ND == LOG2N) {
+    // same thread/slot layout on both sides: multiply in registers
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 g = a.G[tid + s * T];
+      v[s] = cmul(v[s], c64{g.x, g.y});
+    }
+  } else if constexpr (LOG2P < LOG2N) {
+    // spectrum of the zero-stuffed block = periodic repetition of the P-point spectrum
+    // (dft_filter.h:88-103), then the filter
+#pragma unroll
+    for (int h = 0; h < ROUNDS; ++h) {
+      if (fwd_active) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) L.put(tid + s * TF, v[s], h);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) L.get((tid + s * T) & (P - 1), v[s], h);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 g = a.G[tid + s * T];
+      v[s] = cmul(v[s], c64{g.x, g.y});
+    }
+  } else {
+    // frequency-domain decimation by 2^m (dft_filter.h:157-188): keep the lowest and highest
+    // ND/2 bins of the filtered spectrum; the new Nyquist bin is the mean of its two images.
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 g = a.G[tid + s * T];
+      v[s] = cmul(v[s], c64{g.x, g.y});
+    }
+    c64 nyq = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < ROUNDS; ++h) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) L.put(tid + s * T, v[s], h);
+      __syncthreads();
+      if (tid < TD) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int k = tid + s * TD;
+          L.get(k < ND / 2 ? k : N - ND + k, v[s], h);
+        }
+        if (tid == 0) L.get(ND / 2, nyq, h);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) v[8] = {0.5 * (v[8].x + nyq.x), 0.5 * (v[8].y + nyq.y)};
+  }
+
+  const bool inv_active = tid < TD;
+  fft_regs<LOG2ND, +1, SPLIT>(v, tid, inv_active, a.tw_inv, lds);
+
+  if (inv_active) {
+    const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+    if (a.M == 1) {
+      const long long base = a.out_offset + B * a.Vout;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int n = tid + s * TD;
+        if (n < a.Vout) {
+          fifo_put(oa, base + n, v[s].x);
+          if (hasb) fifo_put(ob, base + n, v[s].y);
+        }
+      }
+    } else { // time-domain decimation (dft_filter.h:148-154): keep filtered samples Y with Y % M == 0
+      const long long Y0 = B * a.V;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int n = tid + s * TD;
+        const long long Y = Y0 + n;
+        if (n < a.V && Y % a.M == 0) {
+          fifo_put(oa, a.out_offset + Y / a.M, v[s].x);
+          if (hasb) fifo_put(ob, a.out_offset + Y / a.M, v[s].y);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Polyphase stage.  One workgroup = one tile of consecutive outputs of one channel; the input window
+// of the tile is staged in LDS as fp64, coefficients come from the (L2-resident) table.
+// ---------------------------------------------------------------------------------------------
+template <int ORDER> __global__ __launch_bounds__(256) void poly_kernel(AnyView in, AnyView out, PolyArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double win[];
+  const int tid = threadIdx.x, c = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * a.tile;
+  const int cnt = (int)min((long long)a.tile, a.count - i0);
+  const ChanRef src = chan_ref(in, c), dst = chan_ref(out, c);
+
+  const long long A0 = a.at + i0 * a.step, A1 = a.at + (i0 + cnt - 1) * a.step;
+  const long long q0 = ORDER == 0 ? A0 / a.L : (A0 >> 32);
+  const long long q1 = ORDER == 0 ? A1 / a.L : (A1 >> 32);
+  const int wlen = (int)(q1 - q0) + a.n;
+  for (int i = tid; i < wlen; i += 256) win[i] = fifo_get(src, a.rd + q0 + i);
+  __syncthreads();
+
+  for (int u = tid; u < cnt; u += 256) {
+    const long long A = a.at + (i0 + u) * a.step;
+    double sum = 0.0;
+    if (ORDER == 0) {
+      const long long q = A / a.L;
+      const int ph = (int)(A - q * a.L);
+      const double *__restrict__ cf = a.tab + (long long)ph * a.n;
+      const double *x = win + (q - q0);
+      for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
+    } else {
+      const long long q = A >> 32;
+      const unsigned frac = (unsigned)A;
+      const int ph = (int)(frac >> (32 - a.phase_bits));
+      const double t = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
+      const double *__restrict__ cf = a.tab + (long long)ph * a.n * (ORDER + 1);
+      const double *x = win + (q - q0);
+      for (int j = 0; j < a.n; ++j, cf += ORDER + 1) {
+        double w = cf[0];
+#pragma unroll
+        for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[o]);
+        sum = fma(w, x[j], sum);
+      }
+    }
+    fifo_put(dst, a.out_abs + i0 + u, sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half-band stage: y[i] = .5 x[c] + sum_k coef[k] (x[c-(2k+1)] + x[c+(2k+1)]),  c = rd + pre + 2 i
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void half_kernel(AnyView in, AnyView out, HalfArgs a)
+{
+  const int c = blockIdx.y;
+  const ChanRef src = chan_ref(in, c), dst = chan_ref(out, c);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (long long)gridDim.x * 256) {
+    const long long ctr = a.rd + a.pre + 2 * i;
+    double sum = fifo_get(src, ctr) * 0.5;
+    for (int k = 0; k < a.ncoef; ++k)
+      sum += (fifo_get(src, ctr - (2 * k + 1)) + fifo_get(src, ctr + (2 * k + 1))) * a.coef[k];
+    fifo_put(dst, a.out_abs + i, sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic fifo-to-fifo copy of an absolute index range (small: ring growth, input carry, device pull)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_kernel(AnyView in, AnyView out, long long a0, long long a1)
+{
+  const int c = blockIdx.y;
+  const ChanRef src = chan_ref(in, c), dst = chan_ref(out, c);
+  for (long long a = a0 + (long long)blockIdx.x * 256 + threadIdx.x; a < a1; a += (long long)gridDim.x * 256)
+    fifo_put(dst, a, fifo_get(src, a));
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static AnyView make_view(bool is_f32, const F32View &f, const F64View &d)
+{
+  AnyView v;
+  v.is_f32 = is_f32 ? 1 : 0;
+  v.f = f;
+  v.d = d;
+  return v;
+}
+
+template <int LOG2N, int LOG2P, int LOG2ND>
+static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
+{
+  constexpr int N = 1 << LOG2N;
+  constexpr size_t lds_bytes = (LOG2N >= 14 ? 8 : 16) * size_t(N);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid(a.nblocks, (a.C + 1) / 2), block(N / 16);
+  hipLaunchKernelGGL((dft_kernel<LOG2N, LOG2P, LOG2ND>), grid, block, lds_bytes, st, in, out, a);
+  return hipGetLastError();
+}
+
+#define RSMP_DFT_CASE(n, p, d) \
+  if (log2n == n && log2p == p && log2nd == d) return launch_dft_t<n, p, d>(in, out, a, st);
+#define RSMP_DFT_SIZE(n)    \
+  RSMP_DFT_CASE(n, n, n)     \
+  RSMP_DFT_CASE(n, n - 1, n) \
+  RSMP_DFT_CASE(n, n - 2, n) \
+  RSMP_DFT_CASE(n, n, n - 1) \
+  RSMP_DFT_CASE(n, n, n - 2)
+
+bool dft_shape_supported(int log2n, int log2p, int log2nd)
+{
+  if (log2n < 11 || log2n > 14) return false;
+  if (log2p == log2n) return log2nd >= log2n - 2 && log2nd <= log2n;
+  return log2nd == log2n && log2p >= log2n - 2;
+}
+
+hipError_t launch_dft(int log2n, int log2p, int log2nd, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
+                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st)
+{
+  const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  RSMP_DFT_SIZE(11)
+  RSMP_DFT_SIZE(12)
+  RSMP_DFT_SIZE(13)
+  RSMP_DFT_SIZE(14)
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                       const F64View &dd, const PolyArgs &a, hipStream_t st)
+{
+  const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  const long long tiles = (a.count + a.tile - 1) / a.tile;
+  dim3 grid((unsigned)tiles, a.C), block(256);
+  const size_t lds_bytes = sizeof(double) * size_t(a.win);
+  switch (order) {
+    case 0: hipLaunchKernelGGL(poly_kernel<0>, grid, block, lds_bytes, st, in, out, a); break;
+    case 1: hipLaunchKernelGGL(poly_kernel<1>, grid, block, lds_bytes, st, in, out, a); break;
+    case 2: hipLaunchKernelGGL(poly_kernel<2>, grid, block, lds_bytes, st, in, out, a); break;
+    case 3: hipLaunchKernelGGL(poly_kernel<3>, grid, block, lds_bytes, st, in, out, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
+                       long long a1, int C, hipStream_t st)
+{
+  if (a1 <= a0) return hipSuccess;
+  const AnyView in = make_view(f32, sf, sd), out = make_view(f32, df, dd);
+  long long blocks = (a1 - a0 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks, C), block(256);
+  hipLaunchKernelGGL(copy_kernel, grid, block, 0, st, in, out, a0, a1);
+  return hipGetLastError();
+}
+
+hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                       const F64View &dd, const HalfArgs &a, hipStream_t st)
+{
+  const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  long long blocks = (a.count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  dim3 grid((unsigned)blocks, a.C), block(256);
+  hipLaunchKernelGGL(half_kernel, grid, block, 0, st, in, out, a);
+  return hipGetLastError();
+}
+
+} // namespace rsmp

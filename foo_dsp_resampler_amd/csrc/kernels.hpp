@@ -1,0 +1,79 @@
+// Kernel argument blocks and launch entry points (implemented in kernels.hip).
+//
+// Coordinates: every fifo between stages is addressed by ABSOLUTE sample index since the stream was
+// opened (the preload zeros of rate_base.h:417-422 occupy indices [0, preload)).  Rings are powers of
+// two, so index -> address is `idx & mask`.  All channels of a handle advance in lock step, which is
+// why one set of indices serves every channel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rsmp {
+
+// Interleaved float32 frames: the caller-facing end of the chain (stage-0 input or final output).
+// A frame with absolute index a lives in the external buffer when ext != nullptr and
+// ext_begin <= a < ext_end, else in the ring.  This is what lets a device-resident push be
+// consumed in place and a device-resident pull be produced in place (no staging copy of bulk data).
+struct F32View {
+  float *ring;
+  long long ring_mask;          // frames - 1
+  long long ring_stream_stride; // floats between streams
+  float *ext;
+  long long ext_begin, ext_end; // absolute frame range held by ext
+  long long ext_stream_stride;  // floats between streams
+  int nch;                      // channels per stream
+};
+
+// Planar fp64 ring between two stages: [channel][cap].
+struct F64View {
+  double *ring;
+  long long mask;        // items - 1
+  long long chan_stride; // items between channels
+};
+
+struct DftArgs {
+  const double2 *G;      // N entries: DFT_N(L * h_placed) / N, natural order, e^{-i} convention
+  const double2 *tw_fwd; // twiddle table for the forward size P
+  const double2 *tw_inv; // twiddle table for the inverse size Nd
+  long long B0;          // absolute index of the first block of this launch
+  long long out_offset;  // preload of the destination fifo (absolute index of stage output 0)
+  int nblocks;
+  int C;                 // total channels (streams * nch)
+  int L;                 // zero-stuffing factor
+  int c0;                // initial remL (time-domain stuffing phase)
+  int V;                 // N - (taps-1): valid filtered samples per block before decimation
+  int Vout;              // outputs kept per block when M == 1 (V, or the frequency-domain decimated count)
+  int q;                 // inputs consumed per block (frequency-domain paths)
+  int M;                 // time-domain decimation step (1 = none)
+};
+
+struct PolyArgs {
+  const double *tab;     // [phase][tap][order+1]
+  long long rd;          // absolute index of the stage's read pointer
+  long long at;          // clock relative to rd: integer (order 0, units 1/L) or 32.32 fixed point
+  long long step;        // same units as `at`
+  long long out_abs;     // absolute index (in the destination fifo) of output 0 of this launch
+  long long count;       // outputs to produce
+  int C, n, L, phase_bits, tile, win;
+};
+
+struct HalfArgs {
+  long long rd, out_abs, count;
+  int C, ncoef, pre;
+  double coef[13];
+};
+
+// returns hipSuccess or the launch error; `split` selects the 16384-point 8-byte exchange mode
+hipError_t launch_dft(int log2n, int log2p, int log2nd, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
+                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st);
+hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                       const F64View &dd, const PolyArgs &a, hipStream_t st);
+hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                       const F64View &dd, const HalfArgs &a, hipStream_t st);
+bool dft_shape_supported(int log2n, int log2p, int log2nd);
+// element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
+// (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
+hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
+                       long long a1, int C, hipStream_t st);
+
+} // namespace rsmp

@@ -1,0 +1,63 @@
+/* ratelib_amd.h -- additive extensions of the ratelib.h C ABI for GPU-resident data and for many
+ * independent streams per handle.  Nothing here exists in the reference; the closest reference
+ * interfaces are cited so a maintainer can see what each call generalises.
+ *
+ * A "batch" handle holds `nstreams` independent streams of `nchannels` channels each, all with the
+ * same RR_config and all pushed in lock step (the reference would use nstreams separate handles:
+ * rate/rate_base.h:533-540 makes every channel an independent rate_t already).  Buffers are laid out
+ * [stream][frame][channel]; `*_stride` is the distance between consecutive streams in FRAMES.
+ */
+#ifndef RATELIB_AMD_H
+#define RATELIB_AMD_H
+
+#include "ratelib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Generalises RR_open (rate/ratelib.h:74) to nstreams lock-stepped streams. RR_push/RR_pull/RR_flow
+ * on such a handle use packed host buffers (stride = the frame count of the call). */
+int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle);
+
+/* Device-pointer forms of RR_push / RR_pull / RR_flow (rate/ratelib.h:75-77).  Pointers are HBM
+ * addresses valid on the handle's HIP stream; calls only enqueue work (no host synchronisation),
+ * the frame counts they return are exact because availability never depends on sample values.
+ * RRX_flow_device consumes the input in place and writes new output straight into d_obuf. */
+int RRX_push_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, size_t isamp);
+int RRX_pull_device(RR_handle *h, fb_sample_t *d_obuf, size_t out_stride, size_t osamp, size_t *ogen);
+int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, fb_sample_t *d_obuf, size_t out_stride,
+                    size_t isamp, size_t osamp, size_t *iused, size_t *ogen);
+
+/* Host-pointer forms with an explicit stream stride (batch handles). */
+int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp);
+int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen);
+
+/* Use the caller's hipStream_t (passed as void*) for all work of this handle; NULL restores the
+ * handle's own stream.  RRX_sync blocks until everything enqueued so far has finished. */
+int RRX_set_stream(RR_handle *h, void *hip_stream);
+int RRX_sync(RR_handle *h);
+
+/* Introspection: isamp_max of rate_base.h:531, frames currently pullable (fifo_occupancy of the last
+ * fifo, rate_base.h:447-448), shape of the handle. */
+size_t RRX_isamp_max(const RR_handle *h);
+size_t RRX_available(const RR_handle *h);
+int RRX_channels(const RR_handle *h);
+int RRX_streams(const RR_handle *h);
+
+/* Host-only (no GPU needed): JSON description of the stage chain the planner builds for `config`
+ * (what rate_init decides, rate/rate_base.h:247-423).  Returns the length written (without the
+ * terminator), or the negated RR_error on failure; the text is truncated to cap-1 bytes. */
+int RRX_describe_plan(const RR_config *config, char *buf, size_t cap);
+
+/* Host-only: copy a designed table for `config` into out[0..cap): which = 0 / 1 -> taps of the first /
+ * second DFT-stage filter (after phase conversion, before the 2L/N scaling of rate_base.h:175),
+ * which = 2 -> polyphase table [phase][tap][order+1] (rate/prepare_coefs.h:20-46).  *count receives
+ * the full length.  Returns RR_OK or RR_INVPARAM. */
+int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, size_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,124 @@
+"""CPU-only: the product's host side (planner + filter design, C++) against the independent oracle
+restatement and against the reference-run facts of SURVEY.md; and the C-ABI surface."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+import foo_dsp_resampler_amd as F
+from oracle_binding import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the plugin's rate list (dsp_config.cpp:22)
+RATES = [8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 88200, 96000, 176400, 192000]
+
+
+def test_library_exports_every_declared_symbol():
+    assert F.available_symbols() == F.EXPECTED_SYMBOLS
+    declared = set()
+    for h in ("ratelib.h", "ratelib_amd.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        declared |= set(re.findall(r"\b((?:RRX?_|init_|close_)[A-Za-z_]+)\s*\(", txt))
+    assert declared == set(F.EXPECTED_SYMBOLS), declared ^ set(F.EXPECTED_SYMBOLS)
+
+
+def test_strerror_strings():
+    L = F.lib()
+    want = {0: "OK", 1: "Not enough memory", 2: "Internal error", 3: "NULL handle", 4: "Error in rate() functions",
+            5: "Externals not initialized", 6: "Other error", 99: "Other error"}  # rate_uni.c:92-111
+    for k, v in want.items():
+        assert L.RR_strerror(k).decode() == v
+
+
+def test_null_and_uninitialised_handling_without_gpu():
+    L = F.lib()
+    assert L.RR_push(None, None, 0) == 3 and L.RR_drain(None) == 3 and L.RR_pull(None, None, 0, None) == 3
+    L.RR_close(None)
+    h = C.c_void_p()
+    L.RR_close(C.byref(h))
+    cfg = F.RRConfig(44100, 48000, 50.0, 95.0, 0, 0)
+    assert L.RR_open(C.byref(cfg), 2, None) == 6  # RR_INVPARAM, rate_uni.c:31
+    assert L.init_ratelib(F.ratelib._ALLOC_CB()) == -1  # NULL handler, rate_uni.c:215
+
+
+def plan_key(s):
+    keys = {"dft": ["L", "step_int", "num_taps", "dft_length", "post_peak", "preload", "remL"],
+            "poly": ["L", "step", "at", "n", "interp_order", "preload", "pre_post"],
+            "half": ["n", "pre", "pre_post", "preload"]}[s["kind"]]
+    if s["kind"] == "poly" and s["interp_order"] > 0:
+        keys = keys + ["phase_bits"]
+    return (s["kind"],) + tuple(s[k] for k in keys)
+
+
+def check_against_oracle(fi, fo, tables=True, **kw):
+    got = F.describe_plan(fi, fo, **kw)
+    o = Oracle(fi, fo, 1, **kw)
+    want = o.plan()
+    assert got["isamp_max"] == o.isamp_max
+    assert [plan_key(s) for s in got["stages"]] == [plan_key(s) for s in want], (fi, fo, kw)
+    if tables:
+        for which in (0, 1):
+            a, b = F.plan_table(which, fi, fo, **kw), o.dft_taps(which)
+            assert a.shape == b.shape
+            if a.size:
+                # Linear phase: same libm formulas on both sides -> identical bits.  Other phases go through
+                # the cepstral minimum-phase construction (effects_i_dsp.c:181-278): log|H| of a -180 dB
+                # stop band amplifies the fp64 rounding of whichever FFT is used by ~1e9, so two correct
+                # implementations (and the reference's Ooura FFT) only agree to ~1e-7 of the peak tap.
+                tol = 0 if kw.get("phase", 50.0) == 50.0 else 2e-6
+                assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b))), (fi, fo, kw, which)
+        a, b = F.plan_table(2, fi, fo, **kw), o.poly_table()
+        assert a.shape == b.shape and (a.size == 0 or np.array_equal(a, b)), (fi, fo, kw)
+
+
+@pytest.mark.parametrize("fi,fo", [(a, b) for a, b in itertools.product(RATES, RATES) if a != b])
+def test_rate_matrix_plans_match_oracle(fi, fo):
+    check_against_oracle(fi, fo, tables=False)
+
+
+@pytest.mark.parametrize("fi,fo", [(44100, 48000), (44100, 96000), (44100, 192000), (96000, 44100), (192000, 44100),
+                                   (88200, 44100), (44100, 48001), (48000, 44100), (32000, 96000), (48000, 32000),
+                                   (8000, 192000), (192000, 8000), (44100, 44100), (11025, 44100), (96000, 32000)])
+@pytest.mark.parametrize("kw", [dict(), dict(bandwidth=99.0), dict(bandwidth=90.0, allow_aliasing=1), dict(quality=1),
+                                dict(phase=0.0), dict(phase=25.0), dict(phase=75.0), dict(phase=100.0)])
+def test_tables_match_oracle(fi, fo, kw):
+    check_against_oracle(fi, fo, **kw)
+
+
+def test_survey_facts(facts):
+    for key, want in facts["plans"].items():
+        if key.startswith("_"):
+            continue
+        c = facts["configs"][key]
+        got = F.describe_plan(c["in_rate"], c["out_rate"], phase=c["phase"], bandwidth=c["bandwidth"],
+                              allow_aliasing=c["allow_aliasing"], quality=c["quality"])["stages"]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            for k, v in w.items():
+                if k.startswith("_"):
+                    continue
+                if k == "step_fraction_u32_as_printed":
+                    assert "%.8f" % ((g["step"] & 0xFFFFFFFF) / 1e10) == "0." + v
+                else:
+                    assert g[k] == v, (key, k, g, w)
+    for key, want in facts["design_calls"].items():
+        if key.startswith("_"):
+            continue
+        c = facts["configs"][key]
+        got = F.describe_plan(c["in_rate"], c["out_rate"], bandwidth=c["bandwidth"])["design_calls"]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g["k"] == w["k"] and g["num_taps"] == w["num_taps"]
+            assert abs(g["Fp"] - w["Fp"]) < 1e-10 and abs(g["Fn"] - w["Fn"]) < 1e-9 and abs(g["att"] - w["att"]) < 1e-5
+    assert F.describe_plan(44100, 96000)["isamp_max"] == facts["scalars"]["isamp_max_cfg2"]
+
+
+def test_bad_ratio_is_rejected():
+    with pytest.raises(F.RRError):
+        F.describe_plan(1, 6000)  # factor < 1/5644.8, rate_base.h:528
+    with pytest.raises(F.RRError):
+        F.describe_plan(6000, 1)
