@@ -46,13 +46,36 @@ _alloc_cb = _ALLOC_CB(_alloc_failed)
 _inited = False
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so and load them by file
+    name; a process that also loads /opt/rocm's copy ends up with two HSA runtimes and the second one
+    finds no device.  Loading torch's copy first (same SONAME, libamdhip64.so.7) makes the dynamic
+    linker bind libratelib_amd.so to it, so torch tensors and this engine share one runtime.  Without
+    torch installed the system runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            return C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+    return None
+
+
+_hip_rt = None
+
+
 def lib():
     """Load the shared library (raises if it has not been built: there is no fallback)."""
-    global _lib
+    global _lib, _hip_rt
     if _lib is None:
         p = lib_path()
         if not os.path.exists(p):
             raise RuntimeError("libratelib_amd.so is not built; run `python -m foo_dsp_resampler_amd.build`")
+        _hip_rt = _share_hip_runtime_with_torch()
         L = C.CDLL(p)
         P = C.POINTER
         vp, sz = C.c_void_p, C.c_size_t
