@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -129,12 +130,60 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     }
     if (i + 1 < ns) bytes_per_in_frame += rate * 8.0 * C_;
   }
+  // dft(step 1, L = 1,2,4) directly followed by a rational polyphase stage runs as ONE kernel (fused.hip)
+  fuse_.assign(ns, Fuse());
+  size_t fused_slab_cap = 0;
+  for (int i = 0; i + 1 < ns; ++i) {
+    const StageSpec &d = plan_.stages[i], &p = plan_.stages[i + 1];
+    if (d.kind != StageKind::Dft || p.kind != StageKind::Poly || p.order != 0 || d.step != 1) continue;
+    if (!(d.L == 1 || (pow2_ge2(d.L) && d.L <= 4))) continue;
+    const DftFilter &f = plan_.dft[d.filt];
+    const int log2n = ilog2(f.N), log2p = log2n - (d.L == 1 ? 0 : ilog2(d.L));
+    const int G = 2, pstep = int(p.step64 >> 32), at0 = int(p.at0 >> 32);
+    int dmax = 0;
+    const int NG = (p.L + G - 1) / G;
+    for (int m = 0; m < NG; ++m) {
+      const long long a0 = at0 + (long long)(G * m) * pstep, a1 = at0 + (long long)std::min(G * m + G - 1, p.L - 1) * pstep;
+      dmax = std::max(dmax, int(a1 / p.L - a0 / p.L));
+    }
+    const int threads = f.N / 16;
+    const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
+    if (NG > threads || !fused_shape_supported(log2n, log2p, p.n, p.n + dmax, max_seam)) continue;
+    if (getenv("RSMP_NO_FUSE")) continue;
+    Fuse &fu = fuse_[i];
+    fu.on = true;
+    fu.span = p.n + dmax;
+    fu.NG = NG;
+    fu.KC = threads / NG;
+    fu.slots = 64;
+    const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.seam), bytes));
+    HIP_TRY(hipMemset(fu.seam, 0, bytes));
+    const int V = f.N - (f.num_taps - 1);
+    const size_t per_launch = size_t(fu.slots - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
+    // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
+    double ahead = 1;
+    for (int k = 0; k < i; ++k) ahead *= plan_.stages[k].kind == StageKind::Half ? 0.5 : plan_.stages[k].out_in_ratio;
+    const size_t cap = size_t(double(per_launch) / std::max(ahead, 1e-9));
+    fused_slab_cap = fused_slab_cap ? std::min(fused_slab_cap, cap) : cap;
+  }
+  // the fifo between two fused stages carries no bulk data
+  bytes_per_in_frame = 0;
+  rate = 1;
+  for (int i = 0; i < ns; ++i) {
+    const StageSpec &sp = plan_.stages[i];
+    if (sp.kind == StageKind::Dft) rate *= sp.step > 0 ? double(sp.L) / sp.step : double(sp.L) / double(1 << -sp.step);
+    else if (sp.kind == StageKind::Poly) rate *= sp.out_in_ratio;
+    else rate *= 0.5;
+    if (i + 1 < ns && !fuse_[i].on) bytes_per_in_frame += rate * 8.0 * C_;
+  }
   // Keep the fp64 fifos between stages around the size of the Infinity Cache: a push is cut into
   // time slabs, each slab runs through every stage before the next one starts.
   const double budget = 192.0 * 1024 * 1024;
   slab_frames_ = bytes_per_in_frame > 0 ? size_t(budget / bytes_per_in_frame) : plan_.isamp_max;
   slab_frames_ = std::max<size_t>(slab_frames_, 8192);
   slab_frames_ = std::min<size_t>(slab_frames_, std::max<size_t>(plan_.isamp_max, 1));
+  if (fused_slab_cap) slab_frames_ = std::max<size_t>(1024, std::min(slab_frames_, fused_slab_cap));
   for (int i = 0; i <= ns; ++i)
     if ((rc = ensure_ring(i, std::max<long long>(book_.wr[i], 1))) != kOk) return rc;
   HIP_TRY(hipStreamSynchronize(stream_));
@@ -156,6 +205,7 @@ Engine::~Engine()
   if (d_poly_) (void)hipFree(d_poly_);
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
   if (d_stage_) (void)hipFree(d_stage_);
+  for (Fuse &f : fuse_) if (f.seam) (void)hipFree(f.seam);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -259,6 +309,9 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
   b.wr[0] += (long long)n_new;
   F32View nof = {};
   F64View nod = {};
+  Pending pend;
+  DftArgs pend_args = {};
+  int pend_log2n = 0, pend_log2p = 0;
 
   for (int i = 0; i < ns; ++i) {
     const StageSpec &sp = plan_.stages[i];
@@ -299,9 +352,12 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         ++nblocks;
         ++st.B;
       }
+      const bool fused = fuse_[i].on;
       if (launch && nblocks) {
-        int rc = ensure_ring(i + 1, dst_need(wro));
-        if (rc) return rc;
+        if (!fused) {
+          int rc = ensure_ring(i + 1, dst_need(wro));
+          if (rc) return rc;
+        }
         const int log2n = ilog2(N);
         DftArgs a;
         a.G = d_G_[sp.filt];
@@ -319,6 +375,13 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.Vout = kept;
         a.q = (V - sp.remL0 + L - 1) / L;
         a.M = sp.step > 1 ? sp.step : 1;
+        if (fused) { // launched together with the polyphase stage below
+          pend.B0 = B0;
+          pend.nblocks = nblocks;
+          pend_args = a;
+          pend_log2n = log2n;
+          pend_log2p = log2p;
+        } else
         HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                            src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                            dst_f32 ? nod : f64_view(i + 1), a, stream_));
@@ -330,7 +393,36 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
       const long long lim = sp.order == 0 ? num_in * sp.L : (num_in << 32);
       if (st.at < lim) count = (lim - st.at + step - 1) / step; // rate_filters_generic.h:281 / :477
       at_end = st.at + count * step;
-      if (launch && count) {
+      const bool fused = i > 0 && fuse_[i - 1].on;
+      if (launch && fused) {
+        if ((count != 0) != (pend.nblocks != 0)) return kInternal;
+        if (pend.nblocks) {
+          int rc = ensure_ring(i + 1, dst_need(wro + count));
+          if (rc) return rc;
+          const Fuse &fu = fuse_[i - 1];
+          FusedArgs fa;
+          fa.d = pend_args;
+          fa.tab = d_poly_;
+          fa.seam = fu.seam;
+          fa.at0 = sp.at0 >> 32;
+          fa.b_offset = sp.preload;
+          fa.out_offset2 = out_offset;
+          fa.seam_mask = fu.slots - 1;
+          fa.n = sp.n;
+          fa.polyL = sp.L;
+          fa.step = int(step);
+          fa.span = fu.span;
+          fa.NG = fu.NG;
+          fa.KC = fu.KC;
+          // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
+          const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
+          if (wro + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
+          const bool s32 = i - 1 == 0;
+          HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
+                               s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                               dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+        }
+      } else if (launch && count) {
         int rc = ensure_ring(i + 1, dst_need(wro + count));
         if (rc) return rc;
         PolyArgs a;

@@ -91,6 +91,10 @@ private:
   double *d_poly_ = nullptr;
   double2 *d_tw_[20] = {};
   // staging for host pushes / drains
+  // fused dft->vpoly0 path
+  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0; double *seam = nullptr; int slots = 0; };
+  std::vector<Fuse> fuse_;            // indexed by the dft stage
+  struct Pending { long long B0 = 0; int nblocks = 0; };
   float *d_stage_ = nullptr;
   size_t stage_floats_ = 0;
   size_t slab_frames_ = 0;

@@ -1,0 +1,301 @@
+// Fused hot path for the chain  dft(xL, L in {1,2,4}) -> vpoly0 -> caller  (BASELINE configs 44.1k->48k,
+// 44.1k->96k, 96k->44.1k; reference: rate/dft_filter.h:60-190 followed by
+// rate/rate_filters_generic.h:272-305).
+//
+// One workgroup = one overlap-save block of one channel PAIR (the two channels are the real and
+// imaginary part of one complex transform).  The block's stage-1 samples never leave the CU: after the
+// inverse FFT they are laid out planar in LDS (which replaces the fifo of rate/fifo.h between the two
+// stages) and the polyphase FIR reads them from there.  Only 2*(n-1) samples per block and channel
+// (the block's head and tail) go to a small HBM "seam" ring so that the outputs whose 24-tap window
+// straddles two blocks can be produced by seam_kernel afterwards.
+//
+// Polyphase mapping: outputs i and i + k*L share a phase, hence their coefficients.  A thread owns G
+// consecutive residues r = i mod L and a range of periods k; its G x span coefficients (rows shifted
+// and zero-padded to a common window) live in registers for the whole block, so the inner loop is
+// one LDS read per G (x 2 channels) fp64 FMAs, and no coefficient traffic at all.
+#include "fft_device.hpp"
+#include "fifo_device.hpp"
+#include "kernels.hpp"
+
+namespace rsmp {
+
+constexpr int kPad = 32;      // LDS guard samples around each channel's block
+constexpr int kSpanMax = 32;  // window length (taps + offset spread) the register tile supports
+
+template <int LOG2N, int LOG2P, int G>
+__global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
+{
+  constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
+  constexpr int T = N / 16, TF = P / 16;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int tid = threadIdx.x;
+  const long long B = a.d.B0 + blockIdx.x;
+  const int ca = 2 * blockIdx.y, cb = ca + 1;
+  const bool hasb = cb < a.d.C;
+  const int V = a.d.V;
+
+  // ------------------------------------------------------------------ load the block (fp32 -> fp64)
+  c64 v[16];
+  const bool fwd_active = tid < TF;
+  {
+    const long long e0 = B * a.d.q;
+    bool fast = false;
+    const float2 *p2 = nullptr;
+    if (in.is_f32 && hasb && in.f.nch == 2) { // stereo frame = one complex sample
+      const int s = ca >> 1;
+      if (in.f.ext && e0 >= in.f.ext_begin && e0 + P <= in.f.ext_end) {
+        const float *p = in.f.ext + s * in.f.ext_stream_stride + (e0 - in.f.ext_begin) * 2;
+        fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
+        p2 = reinterpret_cast<const float2 *>(p);
+      } else if ((!in.f.ext || e0 + P <= in.f.ext_begin) && (e0 & in.f.ring_mask) + P <= in.f.ring_mask + 1) {
+        const float *p = in.f.ring + s * in.f.ring_stream_stride + (e0 & in.f.ring_mask) * 2;
+        fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
+        p2 = reinterpret_cast<const float2 *>(p);
+      }
+    }
+    if (fwd_active) {
+      if (fast) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float2 f = p2[tid + s * TF];
+          v[s] = {(double)f.x, (double)f.y};
+        }
+      } else {
+        const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const long long e = e0 + tid + s * TF;
+          v[s].x = fifo_get(ia, e);
+          v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ FFT-FIR (as dft_kernel)
+  fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
+  if constexpr (LOG2P < LOG2N) {
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    if (fwd_active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 z = l2[(tid + s * T) & (P - 1)];
+      v[s] = {z.x, z.y};
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const double2 g = a.d.G[tid + s * T];
+    v[s] = cmul(v[s], c64{g.x, g.y});
+  }
+  fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
+
+  // ------------------------------------------------------------------ stage-1 samples -> LDS (planar)
+  // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
+  double *sA = lds + kPad, *sB = lds + 2 * kPad + V;
+  const int nm1 = a.n - 1;
+  {
+    const int slot = (int)(B & a.seam_mask);
+    double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
+    double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int n = tid + s * T;
+      if (n < V) {
+        sA[n] = v[s].x;
+        sB[n] = v[s].y;
+        if (n < nm1) {
+          seamA[n] = v[s].x;
+          if (hasb) seamB[n] = v[s].y;
+        }
+        if (n >= V - nm1) {
+          seamA[32 + n - (V - nm1)] = v[s].x;
+          if (hasb) seamB[32 + n - (V - nm1)] = v[s].y;
+        }
+      }
+    }
+    if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
+      lds[tid] = 0.0;
+      lds[kPad + V + tid] = 0.0;
+      lds[2 * kPad + 2 * V + tid] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ polyphase FIR from LDS
+  const int pl = a.polyL, step = a.step;
+  const long long b0 = a.b_offset + B * V; // absolute stage-1 index of this block's first sample
+  const long long num_lo = b0 * pl - a.at0, num_hi = (b0 + V - a.n + 1) * pl - a.at0;
+  const long long i_lo = num_lo <= 0 ? 0 : (num_lo + step - 1) / step; // first output whose window starts in the block
+  const long long i_hi = num_hi <= 0 ? 0 : (num_hi + step - 1) / step; // first output whose window leaves the block
+  if (i_hi <= i_lo) return;
+  const long long kk_lo = i_lo / pl, kk_hi = (i_hi - 1) / pl;
+  const int K = (int)(kk_hi - kk_lo) + 1;
+  const int m = tid % a.NG, kc = tid / a.NG;
+  if (kc >= a.KC) return;
+  const int kper = (K + a.KC - 1) / a.KC;
+  const long long kk0 = kk_lo + (long long)kc * kper;
+  const long long kk1 = min(kk0 + kper, kk_hi + 1);
+
+  const int r0 = G * m;
+  long long qr[G];
+  bool rv[G];
+  double cf[G][kSpanMax];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int r = r0 + g;
+    rv[g] = r < pl;
+    const long long ar = a.at0 + (long long)r * step;
+    qr[g] = ar / pl;
+    const int ph = (int)(ar - qr[g] * pl);
+    const int d = (int)(qr[g] - qr[0]);
+    const double *__restrict__ row = a.tab + (long long)ph * a.n;
+#pragma unroll
+    for (int mm = 0; mm < kSpanMax; ++mm) {
+      const int idx = mm - d;
+      cf[g][mm] = (rv[g] && idx >= 0 && idx < a.n) ? row[idx] : 0.0;
+    }
+  }
+
+  // output addressing: stereo float frames written as 8/16-byte vectors when the range is contiguous
+  bool ofast = false;
+  float *obase = nullptr; // points at frame i_lo's first float of this pair
+  {
+    const long long o0 = a.out_offset2 + i_lo, o1 = a.out_offset2 + i_hi;
+    if (out.is_f32 && hasb && out.f.nch == 2) {
+      const int s = ca >> 1;
+      if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
+        obase = out.f.ext + s * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * 2;
+        ofast = true;
+      } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
+                 (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
+        obase = out.f.ring + s * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * 2;
+        ofast = true;
+      }
+      ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
+    }
+  }
+  const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+
+  for (long long kk = kk0; kk < kk1; ++kk) {
+    const long long ibase = kk * pl + r0;
+    bool ok[G], any = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      ok[g] = rv[g] && ibase + g >= i_lo && ibase + g < i_hi;
+      any = any || ok[g];
+    }
+    if (!any) continue;
+    const int li = (int)(qr[0] + kk * step - b0); // >= -kPad because some output of the tile is interior
+    const double *xa = sA + li, *xb = sB + li;
+    double accA[G], accB[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) accA[g] = accB[g] = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < kSpanMax; ++mm) {
+      if (mm < a.span) {
+        const double va = xa[mm], vb = xb[mm];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          accA[g] = fma(cf[g][mm], va, accA[g]);
+          accB[g] = fma(cf[g][mm], vb, accB[g]);
+        }
+      }
+    }
+    if (ofast) {
+      float2 *o2 = reinterpret_cast<float2 *>(obase) + (ibase - i_lo);
+      if (G == 2 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
+        *reinterpret_cast<float4 *>(o2) = make_float4((float)accA[0], (float)accB[0], (float)accA[1], (float)accB[1]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (ok[g]) o2[g] = make_float2((float)accA[g], (float)accB[g]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (ok[g]) {
+          fifo_put(oa, a.out_offset2 + ibase + g, accA[g]);
+          if (hasb) fifo_put(ob, a.out_offset2 + ibase + g, accB[g]);
+        }
+    }
+  }
+}
+
+// Outputs whose window straddles the boundary between block B-1 and block B (or precedes block 0):
+// window samples come from the seam ring.  One thread per (boundary, channel, output).
+__global__ __launch_bounds__(64) void seam_kernel(AnyView out, FusedArgs a)
+{
+  const long long B = a.d.B0 + blockIdx.x;
+  const int c = blockIdx.y;
+  const int nm1 = a.n - 1, pl = a.polyL, step = a.step;
+  const long long b = a.b_offset + B * a.d.V; // first stage-1 index of block B
+  const long long num0 = (b - nm1) * pl - a.at0, num1 = b * pl - a.at0;
+  const long long i0 = num0 <= 0 ? 0 : (num0 + step - 1) / step;
+  const long long i1 = num1 <= 0 ? 0 : (num1 + step - 1) / step;
+  const long long i = i0 + threadIdx.x;
+  if (i >= i1) return;
+  const int slots = a.seam_mask + 1;
+  const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
+  const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
+  const long long ai = a.at0 + i * step, q = ai / pl;
+  const int ph = (int)(ai - q * pl);
+  const double *__restrict__ cf = a.tab + (long long)ph * a.n;
+  const int w0 = (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= w0 < n-1
+  double sum = 0.0;
+  for (int j = 0; j < a.n; ++j) {
+    const int w = w0 + j;
+    const double x = w < nm1 ? (B == 0 ? 0.0 : tail[w]) : head[w - nm1];
+    sum = fma(cf[j], x, sum);
+  }
+  fifo_put(chan_ref(out, c), a.out_offset2 + i, sum);
+}
+
+template <int LOG2N, int LOG2P, int G>
+static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const FusedArgs &a, hipStream_t st)
+{
+  constexpr int N = 1 << LOG2N;
+  constexpr size_t lds_bytes = 16 * size_t(N);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid(a.d.nblocks, (a.d.C + 1) / 2), block(N / 16);
+  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G>), grid, block, lds_bytes, st, in, out, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  dim3 sgrid(a.d.nblocks, a.d.C), sblock(64);
+  hipLaunchKernelGGL(seam_kernel, sgrid, sblock, 0, st, out, a);
+  return hipGetLastError();
+}
+
+bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs)
+{
+  if (log2n < 11 || log2n > 13) return false;
+  if (log2p > log2n || log2p < log2n - 2) return false;
+  return n >= 4 && n <= 32 && span <= kSpanMax && max_seam_outputs <= 64;
+}
+
+#define RSMP_FUSED_CASE(n, p) \
+  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2>(in, out, a, st);
+
+hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
+                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
+{
+  const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  RSMP_FUSED_CASE(11, 11) RSMP_FUSED_CASE(11, 10) RSMP_FUSED_CASE(11, 9)
+  RSMP_FUSED_CASE(12, 12) RSMP_FUSED_CASE(12, 11) RSMP_FUSED_CASE(12, 10)
+  RSMP_FUSED_CASE(13, 13) RSMP_FUSED_CASE(13, 12) RSMP_FUSED_CASE(13, 11)
+  return hipErrorInvalidValue;
+}
+
+} // namespace rsmp

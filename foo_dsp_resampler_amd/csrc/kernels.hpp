@@ -47,6 +47,20 @@ struct DftArgs {
   int M;                 // time-domain decimation step (1 = none)
 };
 
+// dft -> vpoly0 fused launch (fused.hip)
+struct FusedArgs {
+  DftArgs d;             // the FFT-FIR part (out_offset unused)
+  const double *tab;     // polyphase table [phase][tap]
+  double *seam;          // [channel][slot][head|tail][32] stage-1 samples at block edges
+  long long at0;         // absolute initial clock of the poly stage, units 1/polyL
+  long long b_offset;    // preload of the stage-1 fifo (absolute index of the first FFT output)
+  long long out_offset2; // preload of the fifo after the poly stage
+  int seam_mask;         // slots - 1
+  int n, polyL, step;    // taps per phase, phases, clock step
+  int span;              // n + largest window offset inside a G-tile
+  int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
+};
+
 struct PolyArgs {
   const double *tab;     // [phase][tap][order+1]
   long long rd;          // absolute index of the stage's read pointer
@@ -71,6 +85,9 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
 hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
                        const F64View &dd, const HalfArgs &a, hipStream_t st);
 bool dft_shape_supported(int log2n, int log2p, int log2nd);
+hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
+                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
+bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
 hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
