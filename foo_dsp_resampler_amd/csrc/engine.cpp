@@ -414,6 +414,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.span = fu.span;
           fa.NG = fu.NG;
           fa.KC = fu.KC;
+          fa.dbg = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;

@@ -116,23 +116,34 @@ constexpr int fft_twiddle_count(int log2m)
   return n;
 }
 
+// LDS image used by the exchange after the FIRST pass: that pass scatters with a lane stride of R0
+// elements (R0*16 bytes = a multiple of the 128-byte write bank row for R0 >= 8): an 8-way bank
+// conflict on ds_write_b128.  One 16-byte pad per R0 elements makes the lane stride R0+1 elements.
+template <int R0> __device__ __forceinline__ constexpr int lds_phys(int i) { return R0 >= 8 ? i + i / R0 : i; }
+// doubles of LDS an M-point transform needs (non-split) including that padding
+constexpr int fft_lds_doubles(int log2m)
+{
+  const int m = 1 << log2m, r0 = (log2m & 3) ? (1 << (log2m & 3)) : 16;
+  return 2 * (r0 >= 8 ? m + m / r0 : m);
+}
+
 // Exchange the 16 register values through LDS: value in slot s goes to Stockham position pos[s];
 // afterwards slot s holds element tid + s*T.  All threads of the workgroup must call this
 // (barriers); only `active` threads move data.
-template <int T, bool SPLIT>
+template <int T, bool SPLIT, int PADR = 1>
 __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16], int tid, bool active, double *lds)
 {
   if (!SPLIT) {
     double2 *l2 = reinterpret_cast<double2 *>(lds);
     if (active) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) l2[pos[s]] = make_double2(v[s].x, v[s].y);
+      for (int s = 0; s < 16; ++s) l2[lds_phys<PADR>(pos[s])] = make_double2(v[s].x, v[s].y);
     }
     __syncthreads();
     if (active) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        double2 q = l2[tid + s * T];
+        double2 q = l2[lds_phys<PADR>(tid + s * T)];
         v[s] = {q.x, q.y};
       }
     }
@@ -192,7 +203,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
       for (int r = 0; r < R; ++r) pos[t + NB * r] = (j - k) * R + k + r * NS;
     }
-    lds_exchange<T, SPLIT>(v, pos, tid, active, lds);
+    lds_exchange<T, SPLIT, (NS == 1 && !SPLIT) ? R : 1>(v, pos, tid, active, lds);
   }
 }
 

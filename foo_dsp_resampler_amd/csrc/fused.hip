@@ -4,7 +4,7 @@
 //
 // One workgroup = one overlap-save block of one channel PAIR (the two channels are the real and
 // imaginary part of one complex transform).  The block's stage-1 samples never leave the CU: after the
-// inverse FFT they are laid out planar in LDS (which replaces the fifo of rate/fifo.h between the two
+// inverse FFT they stay in LDS as (A,B) pairs, one aligned ds_read_b128 per tap (which replaces the fifo of rate/fifo.h between the two
 // stages) and the polyphase FIR reads them from there.  Only 2*(n-1) samples per block and channel
 // (the block's head and tail) go to a small HBM "seam" ring so that the outputs whose 24-tap window
 // straddles two blocks can be produced by seam_kernel afterwards.
@@ -20,9 +20,11 @@
 namespace rsmp {
 
 constexpr int kPad = 32;      // LDS guard samples around each channel's block
-constexpr int kSpanMax = 32;  // window length (taps + offset spread) the register tile supports
+constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) the register tile supports
 
-template <int LOG2N, int LOG2P, int G>
+// SPAN = window length of a G-tile (compile time, so the whole tap loop is straight-line code and the LDS
+// reads are issued ahead of the FMAs); a.span <= SPAN, coefficients beyond a.span are zero.
+template <int LOG2N, int LOG2P, int G, int SPAN>
 __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
   }
 
   // ------------------------------------------------------------------ FFT-FIR (as dft_kernel)
-  fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
+  if (!(a.dbg & 4)) fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
   if constexpr (LOG2P < LOG2N) {
     double2 *l2 = reinterpret_cast<double2 *>(lds);
     if (fwd_active) {
@@ -94,11 +96,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
     const double2 g = a.d.G[tid + s * T];
     v[s] = cmul(v[s], c64{g.x, g.y});
   }
-  fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
+  if (!(a.dbg & 2)) fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
 
   // ------------------------------------------------------------------ stage-1 samples -> LDS (planar)
   // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
-  double *sA = lds + kPad, *sB = lds + 2 * kPad + V;
+  double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
   const int nm1 = a.n - 1;
   {
     const int slot = (int)(B & a.seam_mask);
@@ -108,8 +110,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
     for (int s = 0; s < 16; ++s) {
       const int n = tid + s * T;
       if (n < V) {
-        sA[n] = v[s].x;
-        sB[n] = v[s].y;
+        smp[n] = make_double2(v[s].x, v[s].y);
         if (n < nm1) {
           seamA[n] = v[s].x;
           if (hasb) seamB[n] = v[s].y;
@@ -121,14 +122,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
       }
     }
     if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
-      lds[tid] = 0.0;
-      lds[kPad + V + tid] = 0.0;
-      lds[2 * kPad + 2 * V + tid] = 0.0;
+      smp[tid - kPad] = make_double2(0.0, 0.0);
+      smp[V + tid] = make_double2(0.0, 0.0);
     }
   }
   __syncthreads();
 
   // ------------------------------------------------------------------ polyphase FIR from LDS
+  if (a.dbg & 1) return;
   const int pl = a.polyL, step = a.step;
   const long long b0 = a.b_offset + B * V; // absolute stage-1 index of this block's first sample
   const long long num_lo = b0 * pl - a.at0, num_hi = (b0 + V - a.n + 1) * pl - a.at0;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
   const int r0 = G * m;
   long long qr[G];
   bool rv[G];
-  double cf[G][kSpanMax];
+  double cf[G][SPAN];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int r = r0 + g;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
     const int d = (int)(qr[g] - qr[0]);
     const double *__restrict__ row = a.tab + (long long)ph * a.n;
 #pragma unroll
-    for (int mm = 0; mm < kSpanMax; ++mm) {
+    for (int mm = 0; mm < SPAN; ++mm) {
       const int idx = mm - d;
       cf[g][mm] = (rv[g] && idx >= 0 && idx < a.n) ? row[idx] : 0.0;
     }
@@ -193,21 +194,21 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
     }
     if (!any) continue;
     const int li = (int)(qr[0] + kk * step - b0); // >= -kPad because some output of the tile is interior
-    const double *xa = sA + li, *xb = sB + li;
+    const double2 *xw = smp + li;
     double accA[G], accB[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) accA[g] = accB[g] = 0.0;
 #pragma unroll
-    for (int mm = 0; mm < kSpanMax; ++mm) {
-      if (mm < a.span) {
-        const double va = xa[mm], vb = xb[mm];
+    for (int mm = 0; mm < SPAN; ++mm) {
+      const double2 xv = xw[mm];
+      const double va = xv.x, vb = xv.y;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          accA[g] = fma(cf[g][mm], va, accA[g]);
-          accB[g] = fma(cf[g][mm], vb, accB[g]);
-        }
+      for (int g = 0; g < G; ++g) {
+        accA[g] = fma(cf[g][mm], va, accA[g]);
+        accB[g] = fma(cf[g][mm], vb, accB[g]);
       }
     }
+    if (a.dbg & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
     if (ofast) {
       float2 *o2 = reinterpret_cast<float2 *>(obase) + (ibase - i_lo);
       if (G == 2 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
@@ -257,20 +258,20 @@ __global__ __launch_bounds__(64) void seam_kernel(AnyView out, FusedArgs a)
   fifo_put(chan_ref(out, c), a.out_offset2 + i, sum);
 }
 
-template <int LOG2N, int LOG2P, int G>
+template <int LOG2N, int LOG2P, int G, int SPAN>
 static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const FusedArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_bytes = 16 * size_t(N);
+  constexpr size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   dim3 grid(a.d.nblocks, (a.d.C + 1) / 2), block(N / 16);
-  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G>), grid, block, lds_bytes, st, in, out, a);
+  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN>), grid, block, lds_bytes, st, in, out, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   dim3 sgrid(a.d.nblocks, a.d.C), sblock(64);
@@ -286,12 +287,17 @@ bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_o
 }
 
 #define RSMP_FUSED_CASE(n, p) \
-  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2>(in, out, a, st);
+  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2, kSpanMax>(in, out, a, st);
+#define RSMP_FUSED_EXACT(n, p, sp) \
+  if (log2n == n && log2p == p && a.span == sp) return launch_fused_t<n, p, 2, sp>(in, out, a, st);
 
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
                         const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  // exact-window variants for the chains the plugin's rate matrix produces at Best (24 taps/phase)
+  RSMP_FUSED_EXACT(12, 11, 25) RSMP_FUSED_EXACT(12, 11, 26) RSMP_FUSED_EXACT(12, 12, 26) RSMP_FUSED_EXACT(12, 12, 27)
+  // generic variants: window padded to kSpanMax
   RSMP_FUSED_CASE(11, 11) RSMP_FUSED_CASE(11, 10) RSMP_FUSED_CASE(11, 9)
   RSMP_FUSED_CASE(12, 12) RSMP_FUSED_CASE(12, 11) RSMP_FUSED_CASE(12, 10)
   RSMP_FUSED_CASE(13, 13) RSMP_FUSED_CASE(13, 12) RSMP_FUSED_CASE(13, 11)

@@ -245,7 +245,7 @@ template <int LOG2N, int LOG2P, int LOG2ND>
 static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_bytes = (LOG2N >= 14 ? 8 : 16) * size_t(N);
+  constexpr size_t lds_bytes = LOG2N >= 14 ? 8 * size_t(N) : 8 * size_t(fft_lds_doubles(LOG2N));
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),

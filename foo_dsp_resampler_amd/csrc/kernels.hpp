@@ -59,6 +59,7 @@ struct FusedArgs {
   int n, polyL, step;    // taps per phase, phases, clock step
   int span;              // n + largest window offset inside a G-tile
   int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
+  int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
 };
 
 struct PolyArgs {
