@@ -159,6 +159,24 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.seam), bytes));
     HIP_TRY(hipMemset(fu.seam, 0, bytes));
+    { // coefficient tiles, one per thread of the fused kernel: tile[mm][g] = row(phase of residue G*m+g)[mm - d_g]
+      std::vector<double> tiles(size_t(32) * G * threads, 0.0);
+      for (int t = 0; t < threads; ++t) {
+        const int m = t % NG, kc = t / NG;
+        if (kc >= fu.KC) continue;
+        const int q0 = (at0 + G * m * pstep) / p.L;
+        for (int g = 0; g < G; ++g) {
+          const int r = G * m + g;
+          if (r >= p.L) continue;
+          const int ar = at0 + r * pstep, q = ar / p.L, ph = ar - q * p.L, dsh = q - q0;
+          for (int j = 0; j < p.n; ++j)
+            if (j + dsh < 32) tiles[(size_t(j + dsh) * G + g) * threads + t] = plan_.poly_table[size_t(ph) * p.n + j];
+        }
+      }
+      void *d = nullptr;
+      if ((rc = upload(tiles.data(), tiles.size() * sizeof(double), &d)) != kOk) return rc;
+      fu.cft = static_cast<double *>(d);
+    }
     const int V = f.N - (f.num_taps - 1);
     const size_t per_launch = size_t(fu.slots - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
     // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
@@ -205,7 +223,10 @@ Engine::~Engine()
   if (d_poly_) (void)hipFree(d_poly_);
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
   if (d_stage_) (void)hipFree(d_stage_);
-  for (Fuse &f : fuse_) if (f.seam) (void)hipFree(f.seam);
+  for (Fuse &f : fuse_) {
+    if (f.seam) (void)hipFree(f.seam);
+    if (f.cft) (void)hipFree(f.cft);
+  }
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -404,6 +425,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.d = pend_args;
           fa.tab = d_poly_;
           fa.seam = fu.seam;
+          fa.cft = fu.cft;
           fa.at0 = sp.at0 >> 32;
           fa.b_offset = sp.preload;
           fa.out_offset2 = out_offset;
@@ -415,6 +437,20 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.NG = fu.NG;
           fa.KC = fu.KC;
           fa.dbg = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
+          fa.pf_dist = getenv("RSMP_PF") ? atoi(getenv("RSMP_PF")) : 0;
+          if (pend.nblocks > kFusedMaxBlocks) return kInternal;
+          for (int k = 0; k < pend.nblocks; ++k) { // output bookkeeping of each block (closed forms, see fused.hip)
+            const long long b0 = fa.b_offset + (pend.B0 + k) * (long long)fa.d.V;
+            const long long nlo = b0 * sp.L - fa.at0, nhi = (b0 + fa.d.V - sp.n + 1) * sp.L - fa.at0;
+            const long long ilo = nlo <= 0 ? 0 : (nlo + step - 1) / step, ihi = nhi <= 0 ? 0 : (nhi + step - 1) / step;
+            FusedBlock &fb = fa.blk[k];
+            fb.i_lo = ilo;
+            fb.cnt = int(std::max<long long>(0, ihi - ilo));
+            const long long kk_lo = ilo / sp.L;
+            fb.irel_lo = int(ilo - kk_lo * sp.L);
+            fb.base_li = int(kk_lo * step - b0);
+            fb.K = fb.cnt > 0 ? int((ihi - 1) / sp.L - kk_lo) + 1 : 0;
+          }
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;

@@ -24,6 +24,10 @@ constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) th
 
 // SPAN = window length of a G-tile (compile time, so the whole tap loop is straight-line code and the LDS
 // reads are issued ahead of the FMAs); a.span <= SPAN, coefficients beyond a.span are zero.
+//
+// Work items w -> (pair = w % npairs, block = w / npairs); by default one workgroup per item.  (A persistent
+// grid with the coefficient tile kept in registers across items was measured 1.6x SLOWER: at the 256-VGPR
+// cap the FFT passes lose their load/compute overlap.)
 template <int LOG2N, int LOG2P, int G, int SPAN>
 __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
@@ -32,199 +36,204 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, An
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   const int tid = threadIdx.x;
-  const long long B = a.d.B0 + blockIdx.x;
-  const int ca = 2 * blockIdx.y, cb = ca + 1;
-  const bool hasb = cb < a.d.C;
+  const int npairs = (a.d.C + 1) >> 1;
+  const int nitems = a.d.nblocks * npairs;
   const int V = a.d.V;
-
-  // ------------------------------------------------------------------ load the block (fp32 -> fp64)
-  c64 v[16];
   const bool fwd_active = tid < TF;
-  {
-    const long long e0 = B * a.d.q;
-    bool fast = false;
-    const float2 *p2 = nullptr;
-    if (in.is_f32 && hasb && in.f.nch == 2) { // stereo frame = one complex sample
-      const int s = ca >> 1;
-      if (in.f.ext && e0 >= in.f.ext_begin && e0 + P <= in.f.ext_end) {
-        const float *p = in.f.ext + s * in.f.ext_stream_stride + (e0 - in.f.ext_begin) * 2;
-        fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
-        p2 = reinterpret_cast<const float2 *>(p);
-      } else if ((!in.f.ext || e0 + P <= in.f.ext_begin) && (e0 & in.f.ring_mask) + P <= in.f.ring_mask + 1) {
-        const float *p = in.f.ring + s * in.f.ring_stream_stride + (e0 & in.f.ring_mask) * 2;
-        fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
-        p2 = reinterpret_cast<const float2 *>(p);
-      }
-    }
-    if (fwd_active) {
-      if (fast) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const float2 f = p2[tid + s * TF];
-          v[s] = {(double)f.x, (double)f.y};
-        }
-      } else {
-        const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const long long e = e0 + tid + s * TF;
-          v[s].x = fifo_get(ia, e);
-          v[s].y = hasb ? fifo_get(ib, e) : 0.0;
-        }
-      }
-    }
-  }
-
-  // ------------------------------------------------------------------ FFT-FIR (as dft_kernel)
-  if (!(a.dbg & 4)) fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
-  if constexpr (LOG2P < LOG2N) {
-    double2 *l2 = reinterpret_cast<double2 *>(lds);
-    if (fwd_active) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const double2 z = l2[(tid + s * T) & (P - 1)];
-      v[s] = {z.x, z.y};
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const double2 g = a.d.G[tid + s * T];
-    v[s] = cmul(v[s], c64{g.x, g.y});
-  }
-  if (!(a.dbg & 2)) fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
-
-  // ------------------------------------------------------------------ stage-1 samples -> LDS (planar)
-  // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
-  double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
+  const double2 *__restrict__ Gp = a.d.G;
+  double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of a block
   const int nm1 = a.n - 1;
-  {
-    const int slot = (int)(B & a.seam_mask);
-    double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
-    double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int n = tid + s * T;
-      if (n < V) {
-        smp[n] = make_double2(v[s].x, v[s].y);
-        if (n < nm1) {
-          seamA[n] = v[s].x;
-          if (hasb) seamB[n] = v[s].y;
-        }
-        if (n >= V - nm1) {
-          seamA[32 + n - (V - nm1)] = v[s].x;
-          if (hasb) seamB[32 + n - (V - nm1)] = v[s].y;
-        }
-      }
-    }
-    if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
-      smp[tid - kPad] = make_double2(0.0, 0.0);
-      smp[V + tid] = make_double2(0.0, 0.0);
-    }
-  }
-  __syncthreads();
 
-  // ------------------------------------------------------------------ polyphase FIR from LDS
-  if (a.dbg & 1) return;
-  const int pl = a.polyL, step = a.step;
-  const long long b0 = a.b_offset + B * V; // absolute stage-1 index of this block's first sample
-  const long long num_lo = b0 * pl - a.at0, num_hi = (b0 + V - a.n + 1) * pl - a.at0;
-  const long long i_lo = num_lo <= 0 ? 0 : (num_lo + step - 1) / step; // first output whose window starts in the block
-  const long long i_hi = num_hi <= 0 ? 0 : (num_hi + step - 1) / step; // first output whose window leaves the block
-  if (i_hi <= i_lo) return;
-  const long long kk_lo = i_lo / pl, kk_hi = (i_hi - 1) / pl;
-  const int K = (int)(kk_hi - kk_lo) + 1;
+  // ------------------------------------------------------------------ per-thread polyphase constants
+  // thread -> (residue group m, period chunk kc); residues r0..r0+G-1 (mod polyL)
+  const int pl = a.polyL, step = a.step, at0 = (int)a.at0;
   const int m = tid % a.NG, kc = tid / a.NG;
-  if (kc >= a.KC) return;
-  const int kper = (K + a.KC - 1) / a.KC;
-  const long long kk0 = kk_lo + (long long)kc * kper;
-  const long long kk1 = min(kk0 + kper, kk_hi + 1);
-
+  const bool poly_thread = kc < a.KC;
   const int r0 = G * m;
-  long long qr[G];
+  const int qr0 = (at0 + r0 * step) / pl;
   bool rv[G];
-  double cf[G][SPAN];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int r = r0 + g;
-    rv[g] = r < pl;
-    const long long ar = a.at0 + (long long)r * step;
-    qr[g] = ar / pl;
-    const int ph = (int)(ar - qr[g] * pl);
-    const int d = (int)(qr[g] - qr[0]);
-    const double *__restrict__ row = a.tab + (long long)ph * a.n;
-#pragma unroll
-    for (int mm = 0; mm < SPAN; ++mm) {
-      const int idx = mm - d;
-      cf[g][mm] = (rv[g] && idx >= 0 && idx < a.n) ? row[idx] : 0.0;
-    }
-  }
+  for (int g = 0; g < G; ++g) rv[g] = r0 + g < pl;
+  const double *__restrict__ cft = a.cft + tid;
 
-  // output addressing: stereo float frames written as 8/16-byte vectors when the range is contiguous
-  bool ofast = false;
-  float *obase = nullptr; // points at frame i_lo's first float of this pair
-  {
-    const long long o0 = a.out_offset2 + i_lo, o1 = a.out_offset2 + i_hi;
-    if (out.is_f32 && hasb && out.f.nch == 2) {
-      const int s = ca >> 1;
-      if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
-        obase = out.f.ext + s * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * 2;
-        ofast = true;
-      } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
-                 (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
-        obase = out.f.ring + s * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * 2;
-        ofast = true;
-      }
-      ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
-    }
-  }
-  const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+  { // one work item per workgroup (see the note above about a persistent loop)
+    const int w = blockIdx.x;
+    if (w >= nitems) return;
+    const int bl = w / npairs, pair = w - bl * npairs;
+    const long long B = a.d.B0 + bl;
+    const int ca = 2 * pair, cb = ca + 1;
+    const bool hasb = cb < a.d.C;
 
-  for (long long kk = kk0; kk < kk1; ++kk) {
-    const long long ibase = kk * pl + r0;
-    bool ok[G], any = false;
+    // ---------------------------------------------------------------- load the block (fp32 -> fp64)
+    c64 v[16];
+    {
+      const long long e0 = B * a.d.q;
+      bool fast = false;
+      const float2 *p2 = nullptr;
+      if (in.is_f32 && hasb && in.f.nch == 2) { // stereo frame = one complex sample
+        if (in.f.ext && e0 >= in.f.ext_begin && e0 + P <= in.f.ext_end) {
+          const float *p = in.f.ext + pair * in.f.ext_stream_stride + (e0 - in.f.ext_begin) * 2;
+          fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
+          p2 = reinterpret_cast<const float2 *>(p);
+        } else if ((!in.f.ext || e0 + P <= in.f.ext_begin) && (e0 & in.f.ring_mask) + P <= in.f.ring_mask + 1) {
+          const float *p = in.f.ring + pair * in.f.ring_stream_stride + (e0 & in.f.ring_mask) * 2;
+          fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
+          p2 = reinterpret_cast<const float2 *>(p);
+        }
+      }
+      if (fwd_active) {
+        if (fast) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      ok[g] = rv[g] && ibase + g >= i_lo && ibase + g < i_hi;
-      any = any || ok[g];
-    }
-    if (!any) continue;
-    const int li = (int)(qr[0] + kk * step - b0); // >= -kPad because some output of the tile is interior
-    const double2 *xw = smp + li;
-    double accA[G], accB[G];
+          for (int s = 0; s < 16; ++s) {
+            const float2 f = p2[tid + s * TF];
+            v[s] = {(double)f.x, (double)f.y};
+          }
+        } else {
+          const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
 #pragma unroll
-    for (int g = 0; g < G; ++g) accA[g] = accB[g] = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < SPAN; ++mm) {
-      const double2 xv = xw[mm];
-      const double va = xv.x, vb = xv.y;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        accA[g] = fma(cf[g][mm], va, accA[g]);
-        accB[g] = fma(cf[g][mm], vb, accB[g]);
+          for (int s = 0; s < 16; ++s) {
+            const long long e = e0 + tid + s * TF;
+            v[s].x = fifo_get(ia, e);
+            v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+          }
+        }
       }
     }
-    if (a.dbg & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
-    if (ofast) {
-      float2 *o2 = reinterpret_cast<float2 *>(obase) + (ibase - i_lo);
-      if (G == 2 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
-        *reinterpret_cast<float4 *>(o2) = make_float4((float)accA[0], (float)accB[0], (float)accA[1], (float)accB[1]);
-      } else {
+
+    // ---------------------------------------------------------------- FFT-FIR (as dft_kernel)
+    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
+    if constexpr (LOG2P < LOG2N) {
+      double2 g[16]; // issued before the exchange so the L2 latency overlaps it
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-          if (ok[g]) o2[g] = make_float2((float)accA[g], (float)accB[g]);
+      for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
+      double2 *l2 = reinterpret_cast<double2 *>(lds);
+      if (fwd_active) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
       }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double2 z = l2[(tid + s * T) & (P - 1)];
+        v[s] = cmul(c64{z.x, z.y}, c64{g[s].x, g[s].y});
+      }
+      __syncthreads();
     } else {
 #pragma unroll
-      for (int g = 0; g < G; ++g)
-        if (ok[g]) {
-          fifo_put(oa, a.out_offset2 + ibase + g, accA[g]);
-          if (hasb) fifo_put(ob, a.out_offset2 + ibase + g, accB[g]);
+      for (int s = 0; s < 16; ++s) {
+        const double2 g = Gp[tid + s * T];
+        v[s] = cmul(v[s], c64{g.x, g.y});
+      }
+    }
+    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
+
+    // coefficient tile of this thread: rows of its G phases shifted to a common window start and zero
+    // padded, pre-arranged by the host as [tap][g][thread] (coalesced, branch-free); issued here so the
+    // L2 latency overlaps the LDS writes below
+    double cf[G][SPAN];
+#pragma unroll
+    for (int mm = 0; mm < SPAN; ++mm)
+#pragma unroll
+      for (int g = 0; g < G; ++g) cf[g][mm] = cft[(mm * G + g) * T];
+
+    // ---------------------------------------------------------------- stage-1 samples -> LDS
+    // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
+    {
+      const int slot = (int)(B & a.seam_mask);
+      double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
+      double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int n = tid + s * T;
+        if (n < V) {
+          smp[n] = make_double2(v[s].x, v[s].y);
+          if (n < nm1) {
+            seamA[n] = v[s].x;
+            if (hasb) seamB[n] = v[s].y;
+          }
+          if (n >= V - nm1) {
+            seamA[32 + n - (V - nm1)] = v[s].x;
+            if (hasb) seamB[32 + n - (V - nm1)] = v[s].y;
+          }
         }
+      }
+      if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
+        smp[tid - kPad] = make_double2(0.0, 0.0);
+        smp[V + tid] = make_double2(0.0, 0.0);
+      }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- polyphase FIR from LDS
+    const FusedBlock fb = a.blk[bl];
+    if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
+      const int irel_hi = fb.irel_lo + fb.cnt;
+      const int kper = (fb.K + a.KC - 1) / a.KC;
+      const int kr0 = kc * kper, kr1 = min(kr0 + kper, fb.K);
+
+      // output addressing: stereo float frames written as 8/16-byte vectors when the range is contiguous
+      bool ofast = false;
+      float *obase = nullptr; // points at frame i_lo's first float of this pair
+      {
+        const long long o0 = a.out_offset2 + fb.i_lo, o1 = o0 + fb.cnt;
+        if (out.is_f32 && hasb && out.f.nch == 2) {
+          if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
+            obase = out.f.ext + pair * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * 2;
+            ofast = true;
+          } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
+                     (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
+            obase = out.f.ring + pair * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * 2;
+            ofast = true;
+          }
+          ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
+        }
+      }
+
+      for (int kr = kr0; kr < kr1; ++kr) {
+        const int ib = kr * pl + r0; // output index relative to period kk_lo
+        bool ok[G], any = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          ok[g] = rv[g] && ib + g >= fb.irel_lo && ib + g < irel_hi;
+          any = any || ok[g];
+        }
+        if (!any) continue;
+        const int li = qr0 + kr * step + fb.base_li; // >= -kPad because some output of the tile is interior
+        const double2 *xw = smp + li;
+        double accA[G], accB[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) accA[g] = accB[g] = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < SPAN; ++mm) {
+          const double2 xv = xw[mm];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            accA[g] = fma(cf[g][mm], xv.x, accA[g]);
+            accB[g] = fma(cf[g][mm], xv.y, accB[g]);
+          }
+        }
+        if (a.dbg & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
+        const int orel = ib - fb.irel_lo; // frame offset from i_lo (-1 for a tile whose first output is a seam output)
+        if (ofast) {
+          float2 *o2 = reinterpret_cast<float2 *>(obase) + orel;
+          if (G == 2 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
+            *reinterpret_cast<float4 *>(o2) = make_float4((float)accA[0], (float)accB[0], (float)accA[1], (float)accB[1]);
+          } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              if (ok[g]) o2[g] = make_float2((float)accA[g], (float)accB[g]);
+          }
+        } else {
+          const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+          const long long oabs = a.out_offset2 + fb.i_lo + orel;
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            if (ok[g]) {
+              fifo_put(oa, oabs + g, accA[g]);
+              if (hasb) fifo_put(ob, oabs + g, accB[g]);
+            }
+        }
+      }
     }
   }
 }
@@ -270,7 +279,8 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  dim3 grid(a.d.nblocks, (a.d.C + 1) / 2), block(N / 16);
+  const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
+  dim3 grid(nitems), block(N / 16);
   hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN>), grid, block, lds_bytes, st, in, out, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

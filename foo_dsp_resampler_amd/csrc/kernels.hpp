@@ -47,10 +47,21 @@ struct DftArgs {
   int M;                 // time-domain decimation step (1 = none)
 };
 
+// per-block output bookkeeping of the fused launch, computed on the host (64-bit divisions stay there)
+struct FusedBlock {
+  long long i_lo; // first output whose window starts inside the block (absolute output index)
+  int cnt;        // number of such outputs whose window also ends inside the block
+  int irel_lo;    // i_lo - kk_lo * polyL, kk_lo = i_lo / polyL (first period touched)
+  int base_li;    // kk_lo * step - b0: window start of (period kk_lo, residue r) is qr(r) + base_li
+  int K;          // periods touched by [i_lo, i_lo + cnt)
+};
+constexpr int kFusedMaxBlocks = 64;
+
 // dft -> vpoly0 fused launch (fused.hip)
 struct FusedArgs {
   DftArgs d;             // the FFT-FIR part (out_offset unused)
   const double *tab;     // polyphase table [phase][tap]
+  const double *cft;     // per-thread coefficient tiles [tap < 32][g < 2][thread], shifted + zero padded
   double *seam;          // [channel][slot][head|tail][32] stage-1 samples at block edges
   long long at0;         // absolute initial clock of the poly stage, units 1/polyL
   long long b_offset;    // preload of the stage-1 fifo (absolute index of the first FFT output)
@@ -60,6 +71,8 @@ struct FusedArgs {
   int span;              // n + largest window offset inside a G-tile
   int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
+  int pf_dist;           // unused (kept for ablation experiments)
+  FusedBlock blk[kFusedMaxBlocks];
 };
 
 struct PolyArgs {
