@@ -27,6 +27,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 IN_RATE, OUT_RATE, NCH = 44100, 96000, 2
 BYTES_PER_UNIT = 4.0 * (1.0 + OUT_RATE / IN_RATE)  # 12.707 B per input channel-sample
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per fused_kernel launch from the PMC passes (profiles/r01_traffic.md); None until measured
+TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def cpu_baseline(seconds_single=4.0, seconds_multi=8.0):
@@ -113,6 +115,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    r.profile(True)   # HIP events around every stage launch, on the launch stream
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,6 +131,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
+    prof = r.profile_read()         # summed per-launch durations of the dominant kernel / the rest
+    r.profile(False)
 
     if dist:
         t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
@@ -138,7 +143,10 @@ def main():
     total_units = units_per_step_rank * args.steps * world
     value = total_units / elapsed / 1e6
     step_dev_s = dev_ms / 1e3 / args.steps
-    achieved_gbs = units_per_step_rank * BYTES_PER_UNIT / step_dev_s / 1e9
+    # dominant kernel = rsmp::fused_kernel (FFT-FIR + polyphase of one block per workgroup); every launch
+    # of a step together covers the step's units, so bytes/launch / avg launch time = step bytes / summed time
+    hot_s = prof["hot_ms"] / 1e3 / args.steps
+    achieved_gbs = units_per_step_rank * BYTES_PER_UNIT / hot_s / 1e9
 
     if rank == 0:
         out = {
@@ -154,10 +162,15 @@ def main():
                        "output_Msamples_per_s": round(value * OUT_RATE / IN_RATE, 2),
                        "out_frames_per_stream": out_frames},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "whole step (all stage kernels of one push), HIP events on the launch stream",
-                         "algorithmic_bytes_per_step": units_per_step_rank * BYTES_PER_UNIT,
-                         "device_ms_per_step": round(step_dev_s * 1e3, 4)},
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                         "kernel": "rsmp::fused_kernel<12,11,2,25> (dft L2 N4096 -> vpoly0 160/147 -> float32)",
+                         "launches_per_step": prof["hot_launches"] / args.steps,
+                         "avg_launch_ms": round(prof["hot_ms"] / max(1, prof["hot_launches"]), 5),
+                         "algorithmic_bytes_per_launch": round(units_per_step_rank * BYTES_PER_UNIT * args.steps
+                                                               / max(1, prof["hot_launches"])),
+                         "other_kernels_ms_per_step": round(prof["other_ms"] / args.steps, 5),
+                         "device_ms_per_step": round(step_dev_s * 1e3, 4),
+                         "whole_step_frac": round(units_per_step_rank * BYTES_PER_UNIT / step_dev_s / 1e9 / HBM_PEAK_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

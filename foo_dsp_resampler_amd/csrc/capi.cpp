@@ -170,6 +170,19 @@ int RRX_sync(RR_handle *h)
   return finish(h->eng->sync());
 }
 
+int RRX_profile(RR_handle *h, int enable)
+{
+  if (!h) return RR_NULLHANDLE;
+  h->eng->set_profiling(enable != 0);
+  return RR_OK;
+}
+
+int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches)
+{
+  if (!h) return RR_NULLHANDLE;
+  return finish(h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches));
+}
+
 size_t RRX_isamp_max(const RR_handle *h) { return h ? h->eng->isamp_max() : 0; }
 size_t RRX_available(const RR_handle *h) { return h ? h->eng->available() : 0; }
 int RRX_channels(const RR_handle *h) { return h ? h->eng->nch() : 0; }

@@ -208,6 +208,55 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   return kOk;
 }
 
+void Engine::set_profiling(bool on)
+{
+  profiling_ = on;
+  for (ProfRec &r : prof_) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  prof_.clear();
+}
+
+int Engine::prof_begin(bool hot)
+{
+  if (!profiling_) return -1;
+  ProfRec r;
+  r.hot = hot;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  (void)hipEventRecord(r.e0, stream_);
+  prof_.push_back(r);
+  return int(prof_.size()) - 1;
+}
+
+void Engine::prof_end(int idx)
+{
+  if (idx >= 0) (void)hipEventRecord(prof_[idx].e1, stream_);
+}
+
+// Sums the recorded launch durations (after synchronising the stream) and clears the records.
+// "hot" = the kernel that carries the bulk of the work of its chain (fused dft->poly, or the dft stage).
+int Engine::read_profile(double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches)
+{
+  HIP_TRY(hipStreamSynchronize(stream_));
+  double h = 0, o = 0;
+  long long hn = 0, on = 0;
+  for (ProfRec &r : prof_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      if (r.hot) { h += ms; ++hn; } else { o += ms; ++on; }
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  prof_.clear();
+  if (hot_ms) *hot_ms = h;
+  if (hot_launches) *hot_launches = hn;
+  if (other_ms) *other_ms = o;
+  if (other_launches) *other_launches = on;
+  return kOk;
+}
+
 void Engine::free_garbage()
 {
   for (void *p : garbage_) (void)hipFree(p);
@@ -222,6 +271,7 @@ Engine::~Engine()
   for (double2 *&g : d_G_) if (g) (void)hipFree(g);
   if (d_poly_) (void)hipFree(d_poly_);
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
+  set_profiling(false);
   if (d_stage_) (void)hipFree(d_stage_);
   for (Fuse &f : fuse_) {
     if (f.seam) (void)hipFree(f.seam);
@@ -402,10 +452,13 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pend_args = a;
           pend_log2n = log2n;
           pend_log2p = log2p;
-        } else
+        } else {
+        const int pi = prof_begin(true);
         HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                            src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                            dst_f32 ? nod : f64_view(i + 1), a, stream_));
+        prof_end(pi);
+        }
       }
     } else if (sp.kind == StageKind::Poly) {
       const long long num_in = std::max<long long>(0, occ - sp.pre_post); // rate_base.h:130
@@ -455,9 +508,14 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
           const bool s32 = i - 1 == 0;
+          const int pi = prof_begin(true);
           HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
                                s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                                dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+          prof_end(pi);
+          const int ps = prof_begin(false);
+          HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+          prof_end(ps);
         }
       } else if (launch && count) {
         int rc = ensure_ring(i + 1, dst_need(wro + count));
@@ -478,9 +536,11 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         while (tile > 256 && (tile * in_per_out + sp.n + 4) * 8 > 48 * 1024) tile >>= 1;
         a.tile = tile;
         a.win = int(tile * in_per_out) + sp.n + 4;
+        const int pi = prof_begin(false);
         HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                             src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                             dst_f32 ? nod : f64_view(i + 1), a, stream_));
+        prof_end(pi);
       }
       if (sp.order == 0) {
         rd += at_end / sp.L; // rate_filters_generic.h:302-304

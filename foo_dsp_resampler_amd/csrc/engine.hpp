@@ -55,6 +55,10 @@ public:
                   size_t *iused, size_t *ogen);
   int drain();
 
+  // optional per-kernel timing: HIP events recorded on the launch stream around every stage launch
+  void set_profiling(bool on);
+  int read_profile(double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches);
+
 private:
   Engine() = default;
   int init(const Config &cfg, int nch, int nstreams);
@@ -95,6 +99,11 @@ private:
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   struct Pending { long long B0 = 0; int nblocks = 0; };
+  struct ProfRec { hipEvent_t e0, e1; bool hot; };
+  std::vector<ProfRec> prof_;
+  bool profiling_ = false;
+  int prof_begin(bool hot);
+  void prof_end(int idx);
   float *d_stage_ = nullptr;
   size_t stage_floats_ = 0;
   size_t slab_frames_ = 0;

@@ -29,7 +29,7 @@ constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) th
 // grid with the coefficient tile kept in registers across items was measured 1.6x SLOWER: at the 256-VGPR
 // cap the FFT passes lose their load/compute overlap.)
 template <int LOG2N, int LOG2P, int G, int SPAN>
-__global__ __launch_bounds__((1 << LOG2N) / 16) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
+__global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
   constexpr int T = N / 16, TF = P / 16;
@@ -282,8 +282,12 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
   const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
   dim3 grid(nitems), block(N / 16);
   hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN>), grid, block, lds_bytes, st, in, out, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
+{
+  const AnyView out = make_view(dst_f32, df, dd);
   dim3 sgrid(a.d.nblocks, a.d.C), sblock(64);
   hipLaunchKernelGGL(seam_kernel, sgrid, sblock, 0, st, out, a);
   return hipGetLastError();

@@ -101,6 +101,8 @@ hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64V
 bool dft_shape_supported(int log2n, int log2p, int log2nd);
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
                         const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
+// seam_kernel: the outputs whose window straddles two blocks; launch after launch_fused on the same stream
+hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)

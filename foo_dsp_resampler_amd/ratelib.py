@@ -13,7 +13,7 @@ RR_BEST, RR_NORM = 0, 1
 EXPECTED_SYMBOLS = [
     "init_ratelib", "close_ratelib", "RR_open", "RR_flow", "RR_push", "RR_pull", "RR_drain", "RR_close", "RR_strerror",
     "RRX_open_batch", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
-    "RRX_set_stream", "RRX_sync", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
+    "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
     "RRX_describe_plan", "RRX_plan_table",
 ]
 
@@ -97,6 +97,8 @@ def lib():
         L.RRX_pull_strided.argtypes = [vp, vp, sz, sz, P(sz)]
         L.RRX_set_stream.argtypes = [vp, vp]
         L.RRX_sync.argtypes = [vp]
+        L.RRX_profile.argtypes = [vp, C.c_int]
+        L.RRX_profile_read.argtypes = [vp, P(C.c_double), P(C.c_longlong), P(C.c_double), P(C.c_longlong)]
         for n in ("RRX_isamp_max", "RRX_available"):
             getattr(L, n).argtypes = [vp]
             getattr(L, n).restype = sz
@@ -195,6 +197,15 @@ class Resampler:
 
     def sync(self):
         _check(self.L.RRX_sync(self.h), "RRX_sync")
+
+    def profile(self, enable=True):
+        _check(self.L.RRX_profile(self.h, 1 if enable else 0), "RRX_profile")
+
+    def profile_read(self):
+        hm, om = C.c_double(0), C.c_double(0)
+        hn, on = C.c_longlong(0), C.c_longlong(0)
+        _check(self.L.RRX_profile_read(self.h, C.byref(hm), C.byref(hn), C.byref(om), C.byref(on)), "RRX_profile_read")
+        return {"hot_ms": hm.value, "hot_launches": hn.value, "other_ms": om.value, "other_launches": on.value}
 
     # -- host API (RR_push / RR_pull / RR_flow / RR_drain)
     def _host_in(self, x):

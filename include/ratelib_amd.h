@@ -38,6 +38,13 @@ int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t 
 int RRX_set_stream(RR_handle *h, void *hip_stream);
 int RRX_sync(RR_handle *h);
 
+/* Per-kernel timing for benchmarks: while enabled, every stage launch is bracketed by HIP events on the
+ * handle's stream.  RRX_profile_read synchronises, returns the summed duration and launch count of the
+ * chain's dominant kernel ("hot": the fused dft->polyphase kernel, or the dft stage) and of all other
+ * stage kernels, and clears the records. */
+int RRX_profile(RR_handle *h, int enable);
+int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches);
+
 /* Introspection: isamp_max of rate_base.h:531, frames currently pullable (fifo_occupancy of the last
  * fifo, rate_base.h:447-448), shape of the handle. */
 size_t RRX_isamp_max(const RR_handle *h);
