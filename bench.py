@@ -28,7 +28,7 @@ IN_RATE, OUT_RATE, NCH = 44100, 96000, 2
 BYTES_PER_UNIT = 4.0 * (1.0 + OUT_RATE / IN_RATE)  # 12.707 B per input channel-sample
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per fused_kernel launch from the PMC passes (profiles/r01_traffic.md); None until measured
-TRAFFIC_BYTES_PER_LAUNCH = None
+TRAFFIC_BYTES_PER_LAUNCH = 645.3e6  # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, mean per launch
 
 
 def cpu_baseline(seconds_single=4.0, seconds_multi=8.0):

@@ -239,32 +239,34 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
 }
 
 // Outputs whose window straddles the boundary between block B-1 and block B (or precedes block 0):
-// window samples come from the seam ring.  One thread per (boundary, channel, output).
-__global__ __launch_bounds__(64) void seam_kernel(AnyView out, FusedArgs a)
+// window samples come from the seam ring.  One workgroup = one boundary x 8 channels, 32 lanes per channel.
+__global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
 {
   const long long B = a.d.B0 + blockIdx.x;
-  const int c = blockIdx.y;
+  const int c = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (c >= a.d.C) return;
   const int nm1 = a.n - 1, pl = a.polyL, step = a.step;
   const long long b = a.b_offset + B * a.d.V; // first stage-1 index of block B
   const long long num0 = (b - nm1) * pl - a.at0, num1 = b * pl - a.at0;
   const long long i0 = num0 <= 0 ? 0 : (num0 + step - 1) / step;
   const long long i1 = num1 <= 0 ? 0 : (num1 + step - 1) / step;
-  const long long i = i0 + threadIdx.x;
-  if (i >= i1) return;
   const int slots = a.seam_mask + 1;
   const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
   const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
-  const long long ai = a.at0 + i * step, q = ai / pl;
-  const int ph = (int)(ai - q * pl);
-  const double *__restrict__ cf = a.tab + (long long)ph * a.n;
-  const int w0 = (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= w0 < n-1
-  double sum = 0.0;
-  for (int j = 0; j < a.n; ++j) {
-    const int w = w0 + j;
-    const double x = w < nm1 ? (B == 0 ? 0.0 : tail[w]) : head[w - nm1];
-    sum = fma(cf[j], x, sum);
+  const ChanRef dst = chan_ref(out, c);
+  for (long long i = i0 + (threadIdx.x & 31); i < i1; i += 32) {
+    const long long ai = a.at0 + i * step, q = ai / pl;
+    const int ph = (int)(ai - q * pl);
+    const double *__restrict__ cf = a.tab + (long long)ph * a.n;
+    const int w0 = (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= w0 < n-1
+    double sum = 0.0;
+    for (int j = 0; j < a.n; ++j) {
+      const int w = w0 + j;
+      const double x = w < nm1 ? (B == 0 ? 0.0 : tail[w]) : head[w - nm1];
+      sum = fma(cf[j], x, sum);
+    }
+    fifo_put(dst, a.out_offset2 + i, sum);
   }
-  fifo_put(chan_ref(out, c), a.out_offset2 + i, sum);
 }
 
 template <int LOG2N, int LOG2P, int G, int SPAN>
@@ -288,7 +290,7 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
 hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
 {
   const AnyView out = make_view(dst_f32, df, dd);
-  dim3 sgrid(a.d.nblocks, a.d.C), sblock(64);
+  dim3 sgrid(a.d.nblocks, (a.d.C + 7) / 8), sblock(256);
   hipLaunchKernelGGL(seam_kernel, sgrid, sblock, 0, st, out, a);
   return hipGetLastError();
 }
