@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=256, help="independent stereo streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="frames per push (default: isamp_max = 481689)")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="strong partition: this many streams split over the ranks (e.g. 1024 = BASELINE configs[4] shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,7 +97,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
+    from foo_dsp_resampler_amd.sharding import shard_range
     S = args.streams
+    if args.total_streams:
+        _, S = shard_range(args.total_streams, world, rank)
     r = F.Resampler(IN_RATE, OUT_RATE, nch=NCH, nstreams=S)
     P = args.frames or r.isamp_max
     P = min(P, r.isamp_max)
@@ -134,13 +139,16 @@ def main():
     prof = r.profile_read()         # summed per-launch durations of the dominant kernel / the rest
     r.profile(False)
 
+    units_per_step_rank = S * P * NCH                    # input channel-samples per step on this GPU
+    units_all = units_per_step_rank
     if dist:
         t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # slowest rank defines the job time
         elapsed, dev_ms = float(t[0]), float(t[1])
-
-    units_per_step_rank = S * P * NCH                    # input channel-samples per step per GPU
-    total_units = units_per_step_rank * args.steps * world
+        u = torch.tensor([float(units_per_step_rank)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        units_all = float(u[0])
+    total_units = units_all * args.steps
     value = total_units / elapsed / 1e6
     step_dev_s = dev_ms / 1e3 / args.steps
     # dominant kernel = rsmp::fused_kernel (FFT-FIR + polyphase of one block per workgroup); every launch
@@ -154,7 +162,7 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 44.1k->96k 2ch float32 Best; %d independent stereo streams "
                                    "per GPU, %d frames per push, device-resident in/out (RRX_flow_device)" % (S, P),

@@ -203,3 +203,62 @@ def test_sine_in_sine_out_on_gpu():
     to = np.arange(m) / fo
     lo, hi = int(.2 * m), int(.8 * m)
     assert np.max(np.abs(y[lo:hi, 0] - np.sin(2 * np.pi * f0 * to[lo:hi]))) < 2e-7
+
+
+def test_tiny_pushes_and_restart_after_drain():
+    """1-frame and odd-sized pushes, a drain with little input, then more input after the drain
+    (the reference keeps going with its zero-padded state, rate_base.h:454-468)."""
+    x = lcg_noise(9000, 2, 3)
+    r, o = F.Resampler(44100, 48000, 2), Oracle(44100, 48000, 2)
+    pos = 0
+    for n in [1, 1, 2, 3, 0, 7, 100, 1, 2047, 1, 1773, 5, 3000]:
+        r.push(x[pos:pos + n]); o.push(x[pos:pos + n])
+        pos += n
+        a, b = r.pull_all(), o.pull_all()
+        assert a.shape == b.shape, n
+        assert_parity(a, b) if a.size else None
+    r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape
+    assert_parity(a, b)
+    r.push(x[pos:pos + 2000]); o.push(x[pos:pos + 2000])
+    r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape
+    assert_parity(a, b)
+
+
+def test_drain_without_input_and_double_drain():
+    r = F.Resampler(44100, 96000, 2)
+    r.drain()
+    assert r.pull_all().shape[0] == 0
+    x = lcg_noise(100, 2, 4)
+    o = Oracle(44100, 96000, 2)
+    r.push(x); o.push(x)
+    r.drain(); o.drain(); r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape == (218, 2)
+    assert_parity(a, b)
+
+
+def test_partial_pulls_preserve_order():
+    x = lcg_noise(12000, 2, 6)
+    r = F.Resampler(44100, 96000, 2)
+    ref = F.Resampler(44100, 96000, 2).process(x)
+    r.push(x)
+    got = []
+    for cap in [1, 7, 1000, 5, 4096, 100000]:
+        got.append(r.pull(cap).copy())
+    r.drain()
+    got.append(r.pull_all())
+    assert np.array_equal(np.concatenate(got), ref)
+
+
+def test_host_throughput_smoke():
+    """PCIe-inclusive path (host pointers): only checks it runs at full isamp_max pushes."""
+    r = F.Resampler(44100, 96000, 2)
+    x = lcg_noise(r.isamp_max, 2, 9)
+    r.push(x)
+    n = r.available
+    y = r.pull(n)
+    assert y.shape[0] == n and np.isfinite(y).all()
