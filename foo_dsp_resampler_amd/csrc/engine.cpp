@@ -392,7 +392,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
     const long long occ = b.wr[i] - rd;
     const bool src_f32 = i == 0, dst_f32 = i + 1 == ns;
     const long long rd_before = rd, wro_before = wro;
-    const long long out_offset = i + 1 < ns ? plan_.stages[i + 1].preload : 0;
+    const long long out_offset = i + 1 < ns ? plan_.stages[i + 1].preload : -b.trimmed;
 
     // what the destination ring must be able to hold once this stage has run
     auto dst_need = [&](long long wr_after) {
@@ -506,7 +506,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           }
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
-          if (wro + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
+          if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
           const bool s32 = i - 1 == 0;
           const int pi = prof_begin(true);
           HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
@@ -780,6 +780,7 @@ int Engine::drain()
     }
     garbage_.push_back(zeros);
   }
+  book_.trimmed += book_.wr.back() - (book_.rd.back() + (long long)remaining);
   book_.wr.back() = book_.rd.back() + (long long)remaining; // fifo_trim_to
   book_.samples_in = book_.samples_out = 0;
   return kOk;

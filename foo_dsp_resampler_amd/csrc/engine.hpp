@@ -25,6 +25,8 @@ struct Book {
   struct St { long long B = 0; int remL = 0, remM = 0; long long at = 0; };
   std::vector<St> st;
   size_t samples_in = 0, samples_out = 0; // rate_base.h:226
+  long long trimmed = 0; // frames fifo_trim_to removed from the last fifo so far (rate_base.h:465): stage outputs are
+                         // indexed absolutely, so the last fifo's positions lag them by this much after a drain
 };
 
 class Engine {

@@ -228,6 +228,19 @@ def test_tiny_pushes_and_restart_after_drain():
     assert_parity(a, b)
 
 
+@pytest.mark.parametrize("fi,fo,kw", [(88200, 44100, {}), (44100, 192000, {"bandwidth": 99.0}), (192000, 44100, {}),
+                                      (48000, 32000, {}), (44100, 48001, {})])
+def test_push_after_drain_other_chains(fi, fo, kw):
+    x = lcg_noise(24000, 2, 11)
+    r, o = F.Resampler(fi, fo, 2, **kw), Oracle(fi, fo, 2, **kw)
+    for lo, hi in [(0, 9000), (9000, 17000), (17000, 24000)]:
+        r.push(x[lo:hi]); o.push(x[lo:hi])
+        r.drain(); o.drain()
+        a, b = r.pull_all(), o.pull_all()
+        assert a.shape == b.shape, (lo, hi)
+        assert_parity(a, b)
+
+
 def test_drain_without_input_and_double_drain():
     r = F.Resampler(44100, 96000, 2)
     r.drain()
