@@ -98,7 +98,7 @@ private:
   double2 *d_tw_[20] = {};
   // staging for host pushes / drains
   // fused dft->vpoly0 path
-  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0; };
+  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   struct Pending { long long B0 = 0; int nblocks = 0; };
   struct ProfRec { hipEvent_t e0, e1; bool hot; };

@@ -47,7 +47,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
   // ------------------------------------------------------------------ per-thread polyphase constants
   // thread -> (residue group m, period chunk kc); residues r0..r0+G-1 (mod polyL)
   const int pl = a.polyL, step = a.step, at0 = (int)a.at0;
-  const int m = tid % a.NG, kc = tid / a.NG;
+  const int item = a.perm[tid]; // host-chosen lane -> (residue group, period chunk) map, see engine.cpp
+  const int m = item % a.NG, kc = item / a.NG;
   const bool poly_thread = kc < a.KC;
   const int r0 = G * m;
   const int qr0 = (at0 + r0 * step) / pl;
@@ -112,10 +113,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
         for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
       }
       __syncthreads();
+      // Z[tid + s*T] = Zp[(tid + s*T) mod P]: only 16/L distinct entries per thread, each used L times
+      constexpr int ND = 16 >> (LOG2N - LOG2P);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const double2 z = l2[(tid + s * T) & (P - 1)];
-        v[s] = cmul(c64{z.x, z.y}, c64{g[s].x, g[s].y});
+      for (int s = 0; s < ND; ++s) {
+        const double2 z = l2[tid + s * T];
+#pragma unroll
+        for (int rep = 0; rep < 16 / ND; ++rep)
+          v[s + rep * ND] = cmul(c64{z.x, z.y}, c64{g[s + rep * ND].x, g[s + rep * ND].y});
       }
       __syncthreads();
     } else {
@@ -168,7 +173,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
     const FusedBlock fb = a.blk[bl];
     if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
       const int irel_hi = fb.irel_lo + fb.cnt;
-      const int kper = (fb.K + a.KC - 1) / a.KC;
+      const int kper = a.kper; // fixed chunk length (not per block) so that the lane map's bank pattern is static
       const int kr0 = kc * kper, kr1 = min(kr0 + kper, fb.K);
 
       // output addressing: stereo float frames written as 8/16-byte vectors when the range is contiguous

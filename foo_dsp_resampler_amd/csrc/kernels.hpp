@@ -70,6 +70,8 @@ struct FusedArgs {
   int n, polyL, step;    // taps per phase, phases, clock step
   int span;              // n + largest window offset inside a G-tile
   int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
+  int kper;              // periods per chunk
+  const int *perm;       // [threads] lane -> item (kc * NG + m), chosen so LDS window reads avoid bank conflicts
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
   int pf_dist;           // unused (kept for ablation experiments)
   FusedBlock blk[kFusedMaxBlocks];
