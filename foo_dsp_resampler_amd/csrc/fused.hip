@@ -71,13 +71,16 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       const long long e0 = B * a.d.q;
       bool fast = false;
       const float2 *p2 = nullptr;
-      if (in.is_f32 && hasb && in.f.nch == 2) { // stereo frame = one complex sample
+      int fstride = 1; // float2 elements between consecutive frames of this channel pair
+      if (in.is_f32 && hasb && !(in.f.nch & 1)) { // channels 2p, 2p+1 sit side by side in every frame
+        const int hp = in.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+        fstride = hp;
         if (in.f.ext && e0 >= in.f.ext_begin && e0 + P <= in.f.ext_end) {
-          const float *p = in.f.ext + pair * in.f.ext_stream_stride + (e0 - in.f.ext_begin) * 2;
+          const float *p = in.f.ext + strm * in.f.ext_stream_stride + (e0 - in.f.ext_begin) * in.f.nch + 2 * pin;
           fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
           p2 = reinterpret_cast<const float2 *>(p);
         } else if ((!in.f.ext || e0 + P <= in.f.ext_begin) && (e0 & in.f.ring_mask) + P <= in.f.ring_mask + 1) {
-          const float *p = in.f.ring + pair * in.f.ring_stream_stride + (e0 & in.f.ring_mask) * 2;
+          const float *p = in.f.ring + strm * in.f.ring_stream_stride + (e0 & in.f.ring_mask) * in.f.nch + 2 * pin;
           fast = (reinterpret_cast<unsigned long long>(p) & 7) == 0;
           p2 = reinterpret_cast<const float2 *>(p);
         }
@@ -86,7 +89,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
         if (fast) {
 #pragma unroll
           for (int s = 0; s < 16; ++s) {
-            const float2 f = p2[tid + s * TF];
+            const float2 f = p2[(tid + s * TF) * fstride];
             v[s] = {(double)f.x, (double)f.y};
           }
         } else {
@@ -179,15 +182,18 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       // output addressing: stereo float frames written as 8/16-byte vectors when the range is contiguous
       bool ofast = false;
       float *obase = nullptr; // points at frame i_lo's first float of this pair
+      int ostride = 1;        // float2 elements between consecutive frames
       {
         const long long o0 = a.out_offset2 + fb.i_lo, o1 = o0 + fb.cnt;
-        if (out.is_f32 && hasb && out.f.nch == 2) {
+        if (out.is_f32 && hasb && !(out.f.nch & 1)) {
+          const int hp = out.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+          ostride = hp;
           if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
-            obase = out.f.ext + pair * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * 2;
+            obase = out.f.ext + strm * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * out.f.nch + 2 * pin;
             ofast = true;
           } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
                      (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
-            obase = out.f.ring + pair * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * 2;
+            obase = out.f.ring + strm * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * out.f.nch + 2 * pin;
             ofast = true;
           }
           ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
@@ -220,13 +226,13 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
         if (a.dbg & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
         const int orel = ib - fb.irel_lo; // frame offset from i_lo (-1 for a tile whose first output is a seam output)
         if (ofast) {
-          float2 *o2 = reinterpret_cast<float2 *>(obase) + orel;
-          if (G == 2 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
+          float2 *o2 = reinterpret_cast<float2 *>(obase) + orel * ostride;
+          if (G == 2 && ostride == 1 && ok[0] && ok[1] && (reinterpret_cast<unsigned long long>(o2) & 15) == 0) {
             *reinterpret_cast<float4 *>(o2) = make_float4((float)accA[0], (float)accB[0], (float)accA[1], (float)accB[1]);
           } else {
 #pragma unroll
             for (int g = 0; g < G; ++g)
-              if (ok[g]) o2[g] = make_float2((float)accA[g], (float)accB[g]);
+              if (ok[g]) o2[g * ostride] = make_float2((float)accA[g], (float)accB[g]);
           }
         } else {
           const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);

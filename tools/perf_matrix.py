@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Throughput of the device-resident path for several chains (not the contract benchmark: see bench.py)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import foo_dsp_resampler_amd as F  # noqa: E402
+
+CASES = [
+    ("cfg0 44.1k->48k 2ch", 44100, 48000, 2, 256, {}),
+    ("cfg1 44.1k->96k 2ch", 44100, 96000, 2, 256, {}),
+    ("cfg2 44.1k->192k 8ch bw99", 44100, 192000, 8, 32, {"bandwidth": 99.0}),
+    ("cfg3 96k->44.1k 32ch", 96000, 44100, 32, 16, {}),
+    ("48k->44.1k 2ch", 48000, 44100, 2, 256, {}),
+    ("88.2k->44.1k 2ch (F-domain /2)", 88200, 44100, 2, 256, {}),
+    ("192k->44.1k 2ch (h12+dft+poly)", 192000, 44100, 2, 128, {}),
+    ("44100->48001 2ch (vpoly3)", 44100, 48001, 2, 128, {}),
+    ("44.1k->48k 2ch Normal", 44100, 48000, 2, 256, {"quality": 1}),
+]
+
+
+def run(name, fi, fo, nch, S, kw, steps=5, frames=200000):
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    P = min(frames, r.isamp_max)
+    st = torch.cuda.current_stream()
+    r.set_stream(st.cuda_stream)
+    x = torch.rand((S, P, nch), device="cuda") - 0.5
+    cap = int(P * fo / fi) + 65536
+    y = torch.empty((S, cap, nch), device="cuda")
+    for _ in range(2):
+        r.flow_device(x, P, y, cap)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.flow_device(x, P, y, cap)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    units = S * P * nch * steps
+    bpu = 4.0 * (1 + fo / fi)
+    plan = [s["kind"] for s in F.describe_plan(fi, fo, **kw)["stages"]]
+    return {"case": name, "plan": "->".join(plan), "Gsamples_in_per_s": round(units / dt / 1e9, 2),
+            "hbm_frac": round(units * bpu / dt / 8e12, 4), "ms_per_step": round(dt / steps * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    for c in CASES:
+        print(json.dumps(run(*c)), flush=True)
