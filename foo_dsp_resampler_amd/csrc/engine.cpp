@@ -83,6 +83,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1) return kUninit; // no HIP device: fail loudly
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   own_stream_ = true;
+  HIP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&ev_fused_, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_seam_[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_seam_[1], hipEventDisableTiming));
 
   const int ns = int(plan_.stages.size());
   book_.wr.assign(ns + 1, 0);
@@ -155,7 +159,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     fu.span = p.n + dmax;
     fu.NG = NG;
     fu.KC = threads / NG;
-    fu.slots = 64;
+    fu.slots = 128; // two launches worth: seam(k) still reads its slots while fused(k+1) fills the next ones
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.seam), bytes));
     HIP_TRY(hipMemset(fu.seam, 0, bytes));
@@ -226,7 +230,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       if ((rc = upload(tiles.data(), tiles.size() * sizeof(double), &d)) != kOk) return rc;
       fu.cft = static_cast<double *>(d);
     }
-    const size_t per_launch = size_t(fu.slots - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
+    const size_t per_launch = size_t(kFusedMaxBlocks - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
     // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
     double ahead = 1;
     for (int k = 0; k < i; ++k) ahead *= plan_.stages[k].kind == StageKind::Half ? 0.5 : plan_.stages[k].out_in_ratio;
@@ -305,6 +309,15 @@ int Engine::read_profile(double *hot_ms, long long *hot_launches, double *other_
   return kOk;
 }
 
+// make the main stream wait for the seam kernels still running on the side stream
+int Engine::join_side()
+{
+  if (!side_pending_) return kOk;
+  HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[(seam_launches_ - 1) & 1], 0)); // the side stream is in order
+  side_pending_ = false;
+  return kOk;
+}
+
 void Engine::free_garbage()
 {
   for (void *p : garbage_) (void)hipFree(p);
@@ -326,6 +339,9 @@ Engine::~Engine()
     if (f.cft) (void)hipFree(f.cft);
     if (f.perm) (void)hipFree(f.perm);
   }
+  if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
+  if (ev_fused_) (void)hipEventDestroy(ev_fused_);
+  for (hipEvent_t &e : ev_seam_) if (e) (void)hipEventDestroy(e);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -377,6 +393,7 @@ int Engine::ensure_ring(int f, long long live_needed)
 {
   Ring &r = rings_[f];
   if (r.buf && r.cap >= live_needed) return kOk;
+  { int rcj = join_side(); if (rcj) return rcj; } // seam kernels on the side stream may still write the old ring
   const long long cap = next_pow2(std::max<long long>({live_needed, r.cap * 2, 4096}));
   const size_t bytes = r.f32 ? size_t(cap) * nch_ * S_ * sizeof(float) : size_t(cap) * C_ * sizeof(double);
   void *nb = nullptr;
@@ -560,14 +577,25 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
           const bool s32 = i - 1 == 0;
+          if (seam_launches_ >= 2) // seam(k-2) read the slots this launch overwrites
+            HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
           const int pi = prof_begin(true);
           HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
                                s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                                dst_f32 ? nod : f64_view(i + 1), fa, stream_));
           prof_end(pi);
-          const int ps = prof_begin(false);
-          HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
-          prof_end(ps);
+          if (profiling_ || getenv("RSMP_NO_SIDE")) { // timing mode: keep everything on one stream
+            const int ps = prof_begin(false);
+            HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+            prof_end(ps);
+          } else {
+            HIP_TRY(hipEventRecord(ev_fused_, stream_));
+            HIP_TRY(hipStreamWaitEvent(side_, ev_fused_, 0));
+            HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, side_));
+            HIP_TRY(hipEventRecord(ev_seam_[seam_launches_ & 1], side_));
+            ++seam_launches_;
+            side_pending_ = true;
+          }
         }
       } else if (launch && count) {
         int rc = ensure_ring(i + 1, dst_need(wro + count));
@@ -653,6 +681,7 @@ int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d
     if (rc) return rc;
     done += n;
   }
+  { int rcj = join_side(); if (rcj) return rcj; }
   // carry the part of this push that no stage has consumed yet into ring 0
   const long long a0 = std::max(book_.rd[0], ein.begin), a1 = book_.wr[0];
   if (a1 > a0) {

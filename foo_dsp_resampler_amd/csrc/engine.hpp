@@ -89,6 +89,12 @@ private:
   int nch_ = 0, S_ = 0, C_ = 0;
   hipStream_t stream_ = nullptr;
   bool own_stream_ = false;
+  // side stream for the seam kernels: seam(k) only depends on fused(k), so it runs beside fused(k+1)
+  hipStream_t side_ = nullptr;
+  hipEvent_t ev_fused_ = nullptr, ev_seam_[2] = {nullptr, nullptr};
+  long long seam_launches_ = 0; // seam launch k records ev_seam_[k & 1]
+  bool side_pending_ = false;
+  int join_side();
   Book book_;
   std::vector<Ring> rings_;
   std::vector<void *> garbage_;
