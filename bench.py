@@ -89,13 +89,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # BENCH_SHARE_GPU=1 / BENCH_BACKEND=gloo: rehearse the multi-rank path on a one-GPU box
+    dev_index = 0 if os.environ.get("BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from foo_dsp_resampler_amd.sharding import shard_range
     S = args.streams
@@ -147,10 +152,11 @@ def main():
     units_per_step_rank = S * P * NCH                    # input channel-samples per step on this GPU
     units_all = units_per_step_rank
     if dist:
-        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
+        rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed, dev_ms], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)       # slowest rank defines the job time
         elapsed, dev_ms = float(t[0]), float(t[1])
-        u = torch.tensor([float(units_per_step_rank)], device="cuda", dtype=torch.float64)
+        u = torch.tensor([float(units_per_step_rank)], device=rdev, dtype=torch.float64)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         units_all = float(u[0])
     total_units = units_all * args.steps

@@ -584,7 +584,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
                                s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
                                dst_f32 ? nod : f64_view(i + 1), fa, stream_));
           prof_end(pi);
-          if (profiling_ || getenv("RSMP_NO_SIDE")) { // timing mode: keep everything on one stream
+          // side stream only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
+          if (profiling_ || !dst_f32 || getenv("RSMP_NO_SIDE")) {
             const int ps = prof_begin(false);
             HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
             prof_end(ps);

@@ -275,3 +275,24 @@ def test_host_throughput_smoke():
     n = r.available
     y = r.pull(n)
     assert y.shape[0] == n and np.isfinite(y).all()
+
+
+RATES = [8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 88200, 96000, 176400, 192000]
+
+
+def test_full_rate_matrix_on_gpu():
+    """Every ordered pair of the plugin's rate list (dsp_config.cpp:22): all chain shapes the planner can
+    produce at Best, short stereo input, frame counts and samples against the oracle."""
+    x = lcg_noise(5000, 2, 21)
+    worst = {"max_ulp": 0.0, "rel_rms": 0.0}
+    for fi in RATES:
+        for fo in RATES:
+            if fi == fo:
+                continue
+            got = F.Resampler(fi, fo, 2).process(x, chunk=1800)
+            ref = Oracle(fi, fo, 2).process(x, chunk=1800)
+            assert got.shape == ref.shape, (fi, fo, got.shape, ref.shape)
+            rep = compare_f32(got, ref)
+            assert rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7, (fi, fo, rep)
+            worst = {k: max(worst[k], rep[k]) for k in worst}
+    print("rate matrix worst case:", worst)
