@@ -296,3 +296,43 @@ def test_full_rate_matrix_on_gpu():
             assert rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7, (fi, fo, rep)
             worst = {k: max(worst[k], rep[k]) for k in worst}
     print("rate matrix worst case:", worst)
+
+
+def test_long_stream_ring_wraparound():
+    """Many small pushes: every device ring wraps several times; output must stay equal to the oracle's."""
+    x = lcg_noise(600000, 2, 31)
+    r, o = F.Resampler(44100, 96000, 2), Oracle(44100, 96000, 2)
+    rm, om = F.Resampler(96000, 44100, 2, **{}), Oracle(96000, 44100, 2)
+    for lo in range(0, 600000, 3001):
+        for a_, b_ in ((r, o), (rm, om)):
+            a_.push(x[lo:lo + 3001]); b_.push(x[lo:lo + 3001])
+            ga, gb = a_.pull_all(), b_.pull_all()
+            assert ga.shape == gb.shape, lo
+            if ga.size:
+                assert_parity(ga, gb)
+    for a_, b_ in ((r, o), (rm, om)):
+        a_.drain(); b_.drain()
+        ga, gb = a_.pull_all(), b_.pull_all()
+        assert ga.shape == gb.shape
+        assert_parity(ga, gb)
+
+
+def test_concurrent_handles_on_threads():
+    """Handles are independent (SURVEY.md 8b 'Threading'): four threads, four handles, different rates."""
+    import threading
+    jobs = [(44100, 96000, 2), (96000, 44100, 2), (44100, 48000, 1), (192000, 44100, 2)]
+    res = [None] * len(jobs)
+
+    def work(k):
+        fi, fo, nch = jobs[k]
+        x = lcg_noise(40000, nch, 100 + k)
+        res[k] = (F.Resampler(fi, fo, nch).process(x, chunk=3333), x)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for k, (fi, fo, nch) in enumerate(jobs):
+        got, x = res[k]
+        ref = Oracle(fi, fo, nch).process(x, chunk=3333)
+        assert got.shape == ref.shape
+        assert_parity(got, ref)
