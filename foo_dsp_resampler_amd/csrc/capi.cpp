@@ -37,6 +37,22 @@ int finish(int rc)
   return rc;
 }
 
+// No C++ exception of ours may cross the C ABI: host-side containers can throw std::bad_alloc, which is
+// reported like any other allocation failure (the handler itself may throw, as the plugin's does; that is the
+// caller's contract, rate/xmalloc.c:38-43).
+template <class Fn> int guarded(Fn fn)
+{
+  int rc;
+  try {
+    rc = fn();
+  } catch (const std::bad_alloc &) {
+    rc = RR_ENOMEM;
+  } catch (...) {
+    rc = RR_INTERNAL;
+  }
+  return finish(rc);
+}
+
 int open_common(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle)
 {
   if (handle == nullptr) return RR_INVPARAM;
@@ -46,7 +62,14 @@ int open_common(const RR_config *config, int nchannels, int nstreams, RR_handle 
   RR_handle *h = new (std::nothrow) RR_handle_tag();
   if (!h) return finish(RR_ENOMEM);
   h->eng = nullptr;
-  int rc = rsmp::Engine::create(to_config(config), nchannels, nstreams, &h->eng);
+  int rc;
+  try {
+    rc = rsmp::Engine::create(to_config(config), nchannels, nstreams, &h->eng);
+  } catch (const std::bad_alloc &) {
+    rc = RR_ENOMEM;
+  } catch (...) {
+    rc = RR_INTERNAL;
+  }
   if (rc != RR_OK) {
     delete h;
     return finish(rc);
@@ -82,27 +105,27 @@ int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_hand
 int RR_push(RR_handle *h, const fb_sample_t *ibuf, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->push_host(ibuf, isamp, isamp));
+  return guarded([&] { return h->eng->push_host(ibuf, isamp, isamp); });
 }
 
 int RR_pull(RR_handle *h, fb_sample_t *obuf, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
   size_t n = osamp < h->eng->available() ? osamp : h->eng->available();
-  return finish(h->eng->pull_host(obuf, n, osamp, ogen));
+  return guarded([&] { return h->eng->pull_host(obuf, n, osamp, ogen); });
 }
 
 int RR_flow(RR_handle *h, const fb_sample_t *ibuf, fb_sample_t *obuf, size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
   if (h->eng->nstreams() != 1) return RR_INVPARAM; // packed layout of a batch is ambiguous here
-  return finish(h->eng->flow_host(ibuf, isamp, obuf, osamp, isamp, osamp, iused, ogen));
+  return guarded([&] { return h->eng->flow_host(ibuf, isamp, obuf, osamp, isamp, osamp, iused, ogen); });
 }
 
 int RR_drain(RR_handle *h)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->drain());
+  return guarded([&] { return h->eng->drain(); });
 }
 
 void RR_close(RR_handle **h)
@@ -129,32 +152,32 @@ const char *RR_strerror(int error)
 int RRX_push_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->push_device(d_ibuf, in_stride, isamp));
+  return guarded([&] { return h->eng->push_device(d_ibuf, in_stride, isamp); });
 }
 
 int RRX_pull_device(RR_handle *h, fb_sample_t *d_obuf, size_t out_stride, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->pull_device(d_obuf, out_stride, osamp, ogen));
+  return guarded([&] { return h->eng->pull_device(d_obuf, out_stride, osamp, ogen); });
 }
 
 int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, fb_sample_t *d_obuf, size_t out_stride,
                     size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->flow_device(d_ibuf, in_stride, d_obuf, out_stride, isamp, osamp, iused, ogen));
+  return guarded([&] { return h->eng->flow_device(d_ibuf, in_stride, d_obuf, out_stride, isamp, osamp, iused, ogen); });
 }
 
 int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->push_host(ibuf, in_stride, isamp));
+  return guarded([&] { return h->eng->push_host(ibuf, in_stride, isamp); });
 }
 
 int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->pull_host(obuf, out_stride, osamp, ogen));
+  return guarded([&] { return h->eng->pull_host(obuf, out_stride, osamp, ogen); });
 }
 
 int RRX_set_stream(RR_handle *h, void *hip_stream)
@@ -167,7 +190,7 @@ int RRX_set_stream(RR_handle *h, void *hip_stream)
 int RRX_sync(RR_handle *h)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->sync());
+  return guarded([&] { return h->eng->sync(); });
 }
 
 int RRX_profile(RR_handle *h, int enable)
@@ -180,7 +203,7 @@ int RRX_profile(RR_handle *h, int enable)
 int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches)
 {
   if (!h) return RR_NULLHANDLE;
-  return finish(h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches));
+  return guarded([&] { return h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches); });
 }
 
 size_t RRX_isamp_max(const RR_handle *h) { return h ? h->eng->isamp_max() : 0; }

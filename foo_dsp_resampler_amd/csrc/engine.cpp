@@ -88,6 +88,8 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   HIP_TRY(hipEventCreateWithFlags(&ev_seam_[0], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_seam_[1], hipEventDisableTiming));
 
+  dbg_ = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
+  no_side_ = getenv("RSMP_NO_SIDE") != nullptr;
   const int ns = int(plan_.stages.size());
   book_.wr.assign(ns + 1, 0);
   book_.rd.assign(ns + 1, 0);
@@ -557,8 +559,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.KC = fu.KC;
           fa.kper = fu.kper;
           fa.perm = fu.perm;
-          fa.dbg = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
-          fa.pf_dist = getenv("RSMP_PF") ? atoi(getenv("RSMP_PF")) : 0;
+          fa.dbg = dbg_;
+          fa.pf_dist = 0;
           if (pend.nblocks > kFusedMaxBlocks) return kInternal;
           for (int k = 0; k < pend.nblocks; ++k) { // output bookkeeping of each block (closed forms, see fused.hip)
             const long long b0 = fa.b_offset + (pend.B0 + k) * (long long)fa.d.V;
@@ -585,7 +587,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
                                dst_f32 ? nod : f64_view(i + 1), fa, stream_));
           prof_end(pi);
           // side stream only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
-          if (profiling_ || !dst_f32 || getenv("RSMP_NO_SIDE")) {
+          if (profiling_ || !dst_f32 || no_side_) {
             const int ps = prof_begin(false);
             HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
             prof_end(ps);

@@ -112,6 +112,8 @@ private:
   bool profiling_ = false;
   int prof_begin(bool hot);
   void prof_end(int idx);
+  int dbg_ = 0;           // RSMP_DBG ablation bits (0 in production)
+  bool no_side_ = false;  // RSMP_NO_SIDE: keep seam kernels on the main stream
   float *d_stage_ = nullptr;
   size_t stage_floats_ = 0;
   size_t slab_frames_ = 0;

@@ -17,6 +17,8 @@
 #include "fifo_device.hpp"
 #include "kernels.hpp"
 
+#include <atomic>
+
 namespace rsmp {
 
 constexpr int kPad = 32;      // LDS guard samples around each channel's block
@@ -285,12 +287,12 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
 {
   constexpr int N = 1 << LOG2N;
   constexpr size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
+  if (!attr_done.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.store(true, std::memory_order_release);
   }
   const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
   dim3 grid(nitems), block(N / 16);

@@ -11,6 +11,8 @@
 // rate/rate_base.h:559-563.
 #include "kernels.hpp"
 
+#include <atomic>
+
 #include "fft_device.hpp"
 #include "fifo_device.hpp"
 
@@ -246,12 +248,12 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
 {
   constexpr int N = 1 << LOG2N;
   constexpr size_t lds_bytes = LOG2N >= 14 ? 8 * size_t(N) : 8 * size_t(fft_lds_doubles(LOG2N));
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
+  if (!attr_done.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.store(true, std::memory_order_release);
   }
   dim3 grid(a.nblocks, (a.C + 1) / 2), block(N / 16);
   hipLaunchKernelGGL((dft_kernel<LOG2N, LOG2P, LOG2ND>), grid, block, lds_bytes, st, in, out, a);

@@ -43,6 +43,31 @@ __global__ void lds_read(double *out, int stride1024, int iters)
   if (sx == 123.456) out[0] = sx + sy;
 }
 
+// ds_read_b64 (forced single reads through inline asm), planar layout, two channels = two reads per tap
+__global__ void lds_read_b64(double *out, int stride1024, int iters)
+{
+  extern __shared__ double2 l2[];
+  double *l1 = reinterpret_cast<double *>(l2);
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) l1[i] = i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int base = ((lane * stride1024) >> 10) + (threadIdx.x >> 6) * 8;
+  double sx = 0, sy = 0;
+  for (int i = 0; i < iters; ++i) {
+    double va[25], vb[25];
+    const unsigned a0 = (unsigned)(((base + i) & 2047) * 8), b0 = a0 + 4096 * 8;
+#pragma unroll
+    for (int u = 0; u < 25; ++u) {
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(va[u]) : "v"(a0), "n"(0 + 8 * u));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vb[u]) : "v"(b0), "n"(0 + 8 * u));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 25; ++u) { sx += va[u]; sy += vb[u]; }
+  }
+  if (sx == 123.456) out[0] = sx + sy;
+}
+
 template <class F> float timeit(F f, int reps = 5)
 {
   hipEvent_t e0, e1;
@@ -87,6 +112,15 @@ int main()
       double instr_per_cu = double(bpc) * 4 * li * 25;
       printf("  blocks/CU %d lane stride %.3f elems: %.3f ms  %.2f cyc/wave-instr/CU\n", bpc, stride / 1024.0, ms,
              ms * 1e-3 * 2.4e9 / instr_per_cu);
+    }
+  printf("ds_read_b64 x2 per tap (planar), cycles per TAP (2 wave-instr) per CU @2.4GHz\n");
+  for (int bpc : {1, 2})
+    for (int stride : {1024, 1882, 3763, 147 * 1024}) {
+      const int blocks = cus * bpc, li = 400;
+      float ms = timeit([&] { hipLaunchKernelGGL(lds_read_b64, dim3(blocks), dim3(256), 65536, 0, d, stride, li); });
+      double taps_per_cu = double(bpc) * 4 * li * 25;
+      printf("  blocks/CU %d lane stride %.3f elems: %.3f ms  %.2f cyc/tap/CU\n", bpc, stride / 1024.0, ms,
+             ms * 1e-3 * 2.4e9 / taps_per_cu);
     }
   return 0;
 }
