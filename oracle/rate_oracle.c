@@ -73,7 +73,9 @@ static const fft_tab *fft_table(int m)
   return t;
 }
 
-/* in-place complex transform, z[2k],z[2k+1] = re,im; Y[k] = sum z[j] exp(sign 2 pi i jk/m) */
+/* in-place complex transform, z[2k],z[2k+1] = re,im; Y[k] = sum z[j] exp(sign 2 pi i jk/m).
+ * Decimation in time: bit reversal, one radix-2 stage when log2(m) is odd, then radix-4 stages
+ * (two radix-2 levels fused: 3 twiddle products per 4 points instead of 4). */
 static void cfft(int m, int sign, double *z)
 {
   const fft_tab *t = fft_table(m);
@@ -86,17 +88,39 @@ static void cfft(int m, int sign, double *z)
       z[2 * r] = a; z[2 * r + 1] = b;
     }
   }
-  for (len = 2; len <= m; len <<= 1) {
-    int half = len >> 1, tstep = m / len;
-    for (i = 0; i < m; i += len) {
-      double *p = z + 2 * i, *q = z + 2 * (i + half);
-      for (k = 0; k < half; ++k) {
-        double wr = t->cs[2 * k * tstep], wi = sign * t->cs[2 * k * tstep + 1];
-        double br = q[2 * k] * wr - q[2 * k + 1] * wi;
-        double bi = q[2 * k] * wi + q[2 * k + 1] * wr;
-        double ar = p[2 * k], ai = p[2 * k + 1];
-        p[2 * k] = ar + br; p[2 * k + 1] = ai + bi;
-        q[2 * k] = ar - br; q[2 * k + 1] = ai - bi;
+  len = 1;
+  if (ilog2(m) & 1) { /* odd number of levels: peel one radix-2 stage (twiddle 1) */
+    for (i = 0; i < m; i += 2) {
+      double ar = z[2 * i], ai = z[2 * i + 1], br = z[2 * i + 2], bi = z[2 * i + 3];
+      z[2 * i] = ar + br; z[2 * i + 1] = ai + bi;
+      z[2 * i + 2] = ar - br; z[2 * i + 3] = ai - bi;
+    }
+    len = 2;
+  }
+  for (; len < m; len <<= 2) { /* combine four sub-transforms of length len into one of 4 len */
+    const int q = len, span = 4 * len, ts1 = m / (2 * len), ts2 = m / (4 * len);
+    for (i = 0; i < m; i += span) {
+      double *p0 = z + 2 * i, *p1 = p0 + 2 * q, *p2 = p1 + 2 * q, *p3 = p2 + 2 * q;
+      for (k = 0; k < q; ++k) {
+        /* level 1 (length 2q) uses w1 = W_{2q}^k on both halves, level 2 (length 4q) uses
+         * w2 = W_{4q}^k and W_{4q}^{k+q} = sign*i*w2 */
+        const double w1r = t->cs[2 * k * ts1], w1i = sign * t->cs[2 * k * ts1 + 1];
+        const double w2r = t->cs[2 * k * ts2], w2i = sign * t->cs[2 * k * ts2 + 1];
+        const double a0r = p0[2 * k], a0i = p0[2 * k + 1];
+        const double b1r = p1[2 * k] * w1r - p1[2 * k + 1] * w1i, b1i = p1[2 * k] * w1i + p1[2 * k + 1] * w1r;
+        const double a2r = p2[2 * k], a2i = p2[2 * k + 1];
+        const double b3r = p3[2 * k] * w1r - p3[2 * k + 1] * w1i, b3i = p3[2 * k] * w1i + p3[2 * k + 1] * w1r;
+        /* level 1 */
+        const double e0r = a0r + b1r, e0i = a0i + b1i, e1r = a0r - b1r, e1i = a0i - b1i; /* first pair: k, k+q  */
+        const double f0r = a2r + b3r, f0i = a2i + b3i, f1r = a2r - b3r, f1i = a2i - b3i; /* second pair        */
+        /* level 2: out[k] = e0 + w2 f0, out[k+2q] = e0 - w2 f0, out[k+q] = e1 + (sign i w2) f1, out[k+3q] = e1 - ... */
+        const double g0r = f0r * w2r - f0i * w2i, g0i = f0r * w2i + f0i * w2r;
+        const double h1r = f1r * w2r - f1i * w2i, h1i = f1r * w2i + f1i * w2r;
+        const double g1r = -sign * h1i, g1i = sign * h1r; /* (sign i) * h1 */
+        p0[2 * k] = e0r + g0r; p0[2 * k + 1] = e0i + g0i;
+        p2[2 * k] = e0r - g0r; p2[2 * k + 1] = e0i - g0i;
+        p1[2 * k] = e1r + g1r; p1[2 * k + 1] = e1i + g1i;
+        p3[2 * k] = e1r - g1r; p3[2 * k + 1] = e1i - g1i;
       }
     }
   }
