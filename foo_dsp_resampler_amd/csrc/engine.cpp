@@ -95,6 +95,8 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   book_.rd.assign(ns + 1, 0);
   book_.st.assign(ns, Book::St());
   rings_.assign(ns + 1, Ring());
+  dftg_.assign(ns, DftGpu());
+  hist_.assign(ns + 1, 0);
   for (int i = 0; i <= ns; ++i) rings_[i].f32 = (i == 0 || i == ns);
 
   double bytes_per_in_frame = 0, rate = 1;
@@ -104,17 +106,28 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     Book::St &st = book_.st[i];
     if (sp.kind == StageKind::Dft) {
       const DftFilter &f = plan_.dft[sp.filt];
-      const int log2n = ilog2(f.N);
+      // Overlap-save is block-size independent: blocks longer than the kernels support run as 16384-point
+      // GPU blocks (needs taps - 1 well below 16384).
+      DftGpu &dg = dftg_[i];
+      dg.Ng = f.N;
+      if (f.N > 16384) {
+        if (f.num_taps - 1 > 16384 - 2048) return kInvParam;
+        dg.Ng = 16384;
+        dg.decoupled = true;
+        hist_[i] = (16384 - (f.num_taps - 1)) / sp.L + 2;
+      }
+      const int Ng = dg.Ng;
+      const int log2n = ilog2(Ng);
       const int log2p = pow2_ge2(sp.L) ? log2n - ilog2(sp.L) : log2n;
       const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
       if (!dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
       st.remL = sp.remL0;
       if (!d_G_[sp.filt]) { // G = DFT_N(L * h placed at (i + N - taps + 1) mod N) / N, rate_base.h:173-175
-        std::vector<cplx> g(f.N);
-        for (int i2 = 0; i2 < f.num_taps; ++i2) g[(i2 + f.N - f.num_taps + 1) & (f.N - 1)] = f.taps[i2] * sp.L;
+        std::vector<cplx> g(Ng);
+        for (int i2 = 0; i2 < f.num_taps; ++i2) g[(i2 + Ng - f.num_taps + 1) & (Ng - 1)] = f.taps[i2] * sp.L;
         fft_inplace(g, -1);
-        std::vector<double2> G(f.N);
-        for (int k = 0; k < f.N; ++k) G[k] = make_double2(g[k].real() / f.N, g[k].imag() / f.N);
+        std::vector<double2> G(Ng);
+        for (int k = 0; k < Ng; ++k) G[k] = make_double2(g[k].real() / Ng, g[k].imag() / Ng);
         void *d = nullptr;
         if ((rc = upload(G.data(), G.size() * sizeof(double2), &d)) != kOk) return rc;
         d_G_[sp.filt] = static_cast<double2 *>(d);
@@ -394,6 +407,7 @@ F64View Engine::f64_view(int f) const
 int Engine::ensure_ring(int f, long long live_needed)
 {
   Ring &r = rings_[f];
+  live_needed += hist_[f]; // a decoupled dft stage re-reads up to hist_ items below the read pointer
   if (r.buf && r.cap >= live_needed) return kOk;
   { int rcj = join_side(); if (rcj) return rcj; } // seam kernels on the side stream may still write the old ring
   const long long cap = next_pow2(std::max<long long>({live_needed, r.cap * 2, 4096}));
@@ -405,7 +419,7 @@ int Engine::ensure_ring(int f, long long live_needed)
     Ring old = r;
     r.buf = nb;
     r.cap = cap;
-    const long long a0 = book_.rd[f], a1 = book_.wr[f];
+    const long long a0 = std::max<long long>(0, book_.rd[f] - hist_[f]), a1 = book_.wr[f];
     F32View sf = {}, df = {};
     F64View sd = {}, dd = {};
     if (r.f32) {
@@ -497,7 +511,10 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           int rc = ensure_ring(i + 1, dst_need(wro));
           if (rc) return rc;
         }
-        const int log2n = ilog2(N);
+        // GPU block geometry: the reference's, or (decoupled) 16384-point blocks over the same absolute stream
+        const DftGpu &dg = dftg_[i];
+        const int Ng = dg.Ng, Vg = Ng - ov;
+        const int log2n = ilog2(Ng);
         DftArgs a;
         a.G = d_G_[sp.filt];
         const int log2p = pow2_ge2(L) ? log2n - ilog2(L) : log2n;
@@ -510,10 +527,25 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.C = C_;
         a.L = L;
         a.c0 = sp.remL0;
-        a.V = V;
-        a.Vout = kept;
-        a.q = (V - sp.remL0 + L - 1) / L;
+        a.V = Vg;
+        a.Vout = sp.step < 0 ? Ng - ((((1 << -sp.step) - 1) * Ng + ov) >> -sp.step) : Vg;
+        a.q = (Vg - sp.remL0 + L - 1) / L;
         a.M = sp.step > 1 ? sp.step : 1;
+        a.in_limit = 0x7fffffffffffffffLL;
+        a.clip_lo = -0x7fffffffffffffffLL;
+        a.clip_hi = 0x7fffffffffffffffLL;
+        if (dg.decoupled) {
+          // filtered-stream positions the reference just made available: [Y0, Y1); GPU blocks that cover them
+          const long long Y0 = B0 * (long long)V, Y1 = (B0 + nblocks) * (long long)V;
+          const long long g0 = Y0 / Vg, g1 = (Y1 - 1) / Vg;
+          a.B0 = g0;
+          a.nblocks = int(g1 - g0 + 1);
+          a.in_limit = b.wr[i]; // a trailing GPU block may reach past the input: zeros there, its late outputs are clipped
+          // stored outputs, in stage-output index units (after any decimation)
+          const long long wr_abs0 = wro_before - out_offset, wr_abs1 = wro - out_offset;
+          a.clip_lo = wr_abs0;
+          a.clip_hi = wr_abs1;
+        }
         if (fused) { // launched together with the polyphase stage below
           pend.B0 = B0;
           pend.nblocks = nblocks;
@@ -686,7 +718,7 @@ int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d
   }
   { int rcj = join_side(); if (rcj) return rcj; }
   // carry the part of this push that no stage has consumed yet into ring 0
-  const long long a0 = std::max(book_.rd[0], ein.begin), a1 = book_.wr[0];
+  const long long a0 = std::max(book_.rd[0] - hist_[0], ein.begin), a1 = book_.wr[0];
   if (a1 > a0) {
     int rc = ensure_ring(0, book_.wr[0] - book_.rd[0]);
     if (rc) return rc;

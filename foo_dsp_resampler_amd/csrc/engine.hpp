@@ -103,6 +103,11 @@ private:
   double *d_poly_ = nullptr;
   double2 *d_tw_[20] = {};
   // staging for host pushes / drains
+  // GPU block length of each dft stage: the reference's N, or 16384 when that is larger ("decoupled":
+  // availability still follows the reference's N, the kernels run their own absolute-anchored blocks)
+  struct DftGpu { int Ng = 0; bool decoupled = false; };
+  std::vector<DftGpu> dftg_;        // indexed by stage
+  std::vector<long long> hist_;     // per fifo: items below rd that must stay readable
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage

@@ -61,8 +61,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const long long e = base + tid + s * TF;
-        v[s].x = fifo_get(ia, e);
-        v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+        const bool have = e < a.in_limit;
+        v[s].x = have ? fifo_get(ia, e) : 0.0;
+        v[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
       }
     } else { // time-domain zero stuffing (dft_filter.h:109-115) in absolute coordinates
       const long long U = B * a.V;
@@ -74,8 +75,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
         v[s] = {0.0, 0.0};
         if (d >= 0 && d % a.L == 0) {
           const long long e = j0 + d / a.L;
-          v[s].x = fifo_get(ia, e);
-          v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+          if (e < a.in_limit) {
+            v[s].x = fifo_get(ia, e);
+            v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+          }
         }
       }
     }
@@ -143,13 +146,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
   if (inv_active) {
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
     if (a.M == 1) {
-      const long long base = a.out_offset + B * a.Vout;
+      const long long o0 = B * a.Vout;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int n = tid + s * TD;
-        if (n < a.Vout) {
-          fifo_put(oa, base + n, v[s].x);
-          if (hasb) fifo_put(ob, base + n, v[s].y);
+        const long long o = o0 + n;
+        if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
+          fifo_put(oa, a.out_offset + o, v[s].x);
+          if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
         }
       }
     } else { // time-domain decimation (dft_filter.h:148-154): keep filtered samples Y with Y % M == 0
@@ -159,8 +163,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
         const int n = tid + s * TD;
         const long long Y = Y0 + n;
         if (n < a.V && Y % a.M == 0) {
-          fifo_put(oa, a.out_offset + Y / a.M, v[s].x);
-          if (hasb) fifo_put(ob, a.out_offset + Y / a.M, v[s].y);
+          const long long o = Y / a.M;
+          if (o >= a.clip_lo && o < a.clip_hi) {
+            fifo_put(oa, a.out_offset + o, v[s].x);
+            if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
+          }
         }
       }
     }

@@ -45,6 +45,9 @@ struct DftArgs {
   int Vout;              // outputs kept per block when M == 1 (V, or the frequency-domain decimated count)
   int q;                 // inputs consumed per block (frequency-domain paths)
   int M;                 // time-domain decimation step (1 = none)
+  // decoupled mode (reference block length > 16384: the GPU runs its own, shorter blocks)
+  long long in_limit;    // input items at absolute index >= in_limit are not there yet: read as zero
+  long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored
 };
 
 // per-block output bookkeeping of the fused launch, computed on the host (64-bit divisions stay there)

@@ -336,3 +336,37 @@ def test_concurrent_handles_on_threads():
         ref = Oracle(fi, fo, nch).process(x, chunk=3333)
         assert got.shape == ref.shape
         assert_parity(got, ref)
+
+
+@pytest.mark.parametrize("fi,fo", [(44100, 8000), (11025, 44100), (8000, 24000), (24000, 8000), (32000, 24000),
+                                   (16000, 11025), (48000, 32000), (8000, 48000), (24000, 32000)])
+def test_long_filters_reference_blocks_of_32768(fi, fo):
+    """bandwidth 99 % makes the reference plan 32768-point DFT blocks for these pairs (dft_stage_init,
+    rate_base.h:171).  The engine runs them as 16384-point GPU blocks over the same absolute stream
+    (overlap-save is block-size independent) while availability still follows the reference's blocks."""
+    plan = F.describe_plan(fi, fo, bandwidth=99.0)
+    big = [s for s in plan["stages"] if s["kind"] == "dft" and s["dft_length"] == 32768]
+    assert big, plan
+    # A stage that decimates in the FREQUENCY domain (step_int < 0, dft_filter.h:157-188) truncates the
+    # spectrum, which equals a true decimation only up to the stop-band leakage (~ -176 dB); that residue
+    # depends on the block length and is an ABSOLUTE error (~1e-9 of full scale, whatever the sample's size), so
+    # for those shapes the bar is relative RMS 1e-8 and 2e-7 absolute instead of 1 ulp.
+    fdomain = any(s["step_int"] < 0 for s in big)
+
+    def check(a, b):
+        if not fdomain:
+            return assert_parity(a, b)
+        rep = compare_f32(a, b)
+        assert rep["rel_rms"] <= 1e-8 and rep["max_abs"] <= 2e-7, rep
+    x = lcg_noise(90000, 2, 41)
+    r, o = F.Resampler(fi, fo, 2, bandwidth=99.0), Oracle(fi, fo, 2, bandwidth=99.0)
+    for lo in range(0, 90000, 23000):
+        r.push(x[lo:lo + 23000]); o.push(x[lo:lo + 23000])
+        a, b = r.pull_all(), o.pull_all()
+        assert a.shape == b.shape, (lo, a.shape, b.shape)
+        if a.size:
+            check(a, b)
+    r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape
+    check(a, b)
