@@ -4,10 +4,10 @@
 //
 // One workgroup = one overlap-save block of one channel PAIR (the two channels are the real and
 // imaginary part of one complex transform).  The block's stage-1 samples never leave the CU: after the
-// inverse FFT they stay in LDS as (A,B) pairs, one aligned ds_read_b128 per tap (which replaces the fifo of rate/fifo.h between the two
-// stages) and the polyphase FIR reads them from there.  Only 2*(n-1) samples per block and channel
-// (the block's head and tail) go to a small HBM "seam" ring so that the outputs whose 24-tap window
-// straddles two blocks can be produced by seam_kernel afterwards.
+// inverse FFT they stay in LDS as (A,B) pairs (this LDS image replaces the fifo of rate/fifo.h between the
+// two stages) and the polyphase FIR reads them from there, one aligned ds_read_b128 per tap.  Only 2*(n-1)
+// samples per block and channel (the block's head and tail) go to a small HBM "seam" ring so that the
+// outputs whose 24-tap window straddles two blocks can be produced by seam_kernel afterwards.
 //
 // Polyphase mapping: outputs i and i + k*L share a phase, hence their coefficients.  A thread owns G
 // consecutive residues r = i mod L and a range of periods k; its G x span coefficients (rows shifted
@@ -27,9 +27,11 @@ constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) th
 // SPAN = window length of a G-tile (compile time, so the whole tap loop is straight-line code and the LDS
 // reads are issued ahead of the FMAs); a.span <= SPAN, coefficients beyond a.span are zero.
 //
-// Work items w -> (pair = w % npairs, block = w / npairs); by default one workgroup per item.  (A persistent
-// grid with the coefficient tile kept in registers across items was measured 1.6x SLOWER: at the 256-VGPR
-// cap the FFT passes lose their load/compute overlap.)
+// Grid: 1-D, one workgroup per work item w -> (pair = w % npairs, block = w / npairs).  Blocks are dealt
+// round-robin over the 8 XCDs, so with npairs % 8 == 0 the consecutive blocks of one pair land on the same
+// XCD and their 2*(taps-1)-sample input overlap is an L2 hit.  (A persistent grid with the coefficient tile
+// kept in registers across items was measured 1.6x SLOWER: at the 256-VGPR cap the FFT passes lose their
+// load/compute overlap.)
 template <int LOG2N, int LOG2P, int G, int SPAN>
 __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {

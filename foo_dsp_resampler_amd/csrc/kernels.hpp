@@ -76,7 +76,7 @@ struct FusedArgs {
   int kper;              // periods per chunk
   const int *perm;       // [threads] lane -> item (kc * NG + m), chosen so LDS window reads avoid bank conflicts
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
-  int pf_dist;           // unused (kept for ablation experiments)
+  int pf_dist;           // reserved (0)
   FusedBlock blk[kFusedMaxBlocks];
 };
 
