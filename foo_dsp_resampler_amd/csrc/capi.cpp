@@ -3,6 +3,7 @@
 #include "../../include/ratelib_amd.h"
 
 #include "engine.hpp"
+#include "plugin_host.hpp"
 
 #include <cstring>
 #include <new>
@@ -234,6 +235,104 @@ int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, 
   if (count) *count = t.size();
   if (out)
     for (size_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
+  return RR_OK;
+}
+
+// ---- plugin layer ----------------------------------------------------------------------------------
+} // extern "C"
+
+struct DSPR_handle_tag {
+  rsmp::DspRate *dsp;
+  std::deque<rsmp::AudioChunk> out;
+};
+
+extern "C" {
+
+int DSPR_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase, DSPR_handle **h)
+{
+  if (!h) return RR_INVPARAM;
+  *h = nullptr;
+  if (!g_initialized) return RR_EXTUNINIT;
+  rsmp::RateSettings s;
+  s.out_rate = out_rate;
+  s.quality = quality;
+  s.allow_aliasing = allow_aliasing;
+  s.passband10 = passband10;
+  s.phase = phase;
+  DSPR_handle *d = new (std::nothrow) DSPR_handle_tag();
+  if (!d) return finish(RR_ENOMEM);
+  d->dsp = new (std::nothrow) rsmp::DspRate(s);
+  if (!d->dsp) {
+    delete d;
+    return finish(RR_ENOMEM);
+  }
+  *h = d;
+  return RR_OK;
+}
+
+void DSPR_destroy(DSPR_handle **h)
+{
+  if (!h || !*h) return;
+  delete (*h)->dsp;
+  delete *h;
+  *h = nullptr;
+}
+
+int DSPR_on_chunk(DSPR_handle *h, const fb_sample_t *data, size_t frames, unsigned channels, unsigned sample_rate,
+                  unsigned channel_config, int *passthrough)
+{
+  if (!h) return RR_NULLHANDLE;
+  return guarded([&] {
+    rsmp::AudioChunk c;
+    c.data.assign(data, data + frames * channels);
+    c.frames = frames;
+    c.channels = channels;
+    c.sample_rate = sample_rate;
+    c.channel_config = channel_config;
+    const bool pass = h->dsp->on_chunk(c, h->out);
+    if (passthrough) *passthrough = pass ? 1 : 0;
+    return h->dsp->last_error();
+  });
+}
+
+int DSPR_end_of_track(DSPR_handle *h)
+{
+  if (!h) return RR_NULLHANDLE;
+  return guarded([&] {
+    h->dsp->on_endoftrack(h->out);
+    return h->dsp->last_error();
+  });
+}
+
+void DSPR_flush(DSPR_handle *h)
+{
+  if (h) h->dsp->flush();
+}
+
+double DSPR_get_latency(const DSPR_handle *h) { return h ? h->dsp->get_latency() : 0.0; }
+
+int DSPR_peek_output(const DSPR_handle *h, size_t *frames, unsigned *channels, unsigned *sample_rate)
+{
+  if (!h) return RR_NULLHANDLE;
+  if (h->out.empty()) {
+    if (frames) *frames = 0;
+    return RR_OK;
+  }
+  const rsmp::AudioChunk &c = h->out.front();
+  if (frames) *frames = c.frames;
+  if (channels) *channels = c.channels;
+  if (sample_rate) *sample_rate = c.sample_rate;
+  return RR_OK;
+}
+
+int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames)
+{
+  if (!h) return RR_NULLHANDLE;
+  if (h->out.empty()) return RR_INVPARAM;
+  const rsmp::AudioChunk &c = h->out.front();
+  if (!dst || cap_frames < c.frames) return RR_INVPARAM;
+  std::memcpy(dst, c.data.data(), c.frames * c.channels * sizeof(float));
+  h->out.pop_front();
   return RR_OK;
 }
 

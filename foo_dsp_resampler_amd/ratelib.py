@@ -15,6 +15,8 @@ EXPECTED_SYMBOLS = [
     "RRX_open_batch", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
     "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
     "RRX_describe_plan", "RRX_plan_table",
+    "DSPR_create", "DSPR_destroy", "DSPR_on_chunk", "DSPR_end_of_track", "DSPR_flush", "DSPR_get_latency",
+    "DSPR_peek_output", "DSPR_pop_output",
 ]
 
 
@@ -104,6 +106,17 @@ def lib():
             getattr(L, n).restype = sz
         L.RRX_channels.argtypes = [vp]
         L.RRX_streams.argtypes = [vp]
+        L.DSPR_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(vp)]
+        L.DSPR_destroy.argtypes = [P(vp)]
+        L.DSPR_destroy.restype = None
+        L.DSPR_on_chunk.argtypes = [vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, P(C.c_int)]
+        L.DSPR_end_of_track.argtypes = [vp]
+        L.DSPR_flush.argtypes = [vp]
+        L.DSPR_flush.restype = None
+        L.DSPR_get_latency.argtypes = [vp]
+        L.DSPR_get_latency.restype = C.c_double
+        L.DSPR_peek_output.argtypes = [vp, P(sz), P(C.c_uint), P(C.c_uint)]
+        L.DSPR_pop_output.argtypes = [vp, vp, sz]
         L.RRX_describe_plan.argtypes = [P(RRConfig), C.c_char_p, sz]
         L.RRX_plan_table.argtypes = [P(RRConfig), C.c_int, vp, sz, P(sz)]
         _lib = L
@@ -288,3 +301,55 @@ class Resampler:
                                       in_stride or in_frames, C.c_void_p(tout.data_ptr()), out_stride or out_cap,
                                       in_frames, out_cap, C.byref(iu), C.byref(og)), "RRX_flow_device")
         return iu.value, og.value
+
+
+class DspRate:
+    """Mirror of the plugin's dsp_rate object (foo_dsp_rate.h:24-80) through the DSPR_* entry points."""
+
+    def __init__(self, out_rate, quality=RR_BEST, allow_aliasing=0, passband10=950, phase=50):
+        _ensure_init()
+        self.L = lib()
+        self.h = C.c_void_p()
+        _check(self.L.DSPR_create(out_rate, quality, allow_aliasing, passband10, phase, C.byref(self.h)), "DSPR_create")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.DSPR_destroy(C.byref(self.h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _drain_queue(self):
+        chunks = []
+        while True:
+            n, ch, sr = C.c_size_t(0), C.c_uint(0), C.c_uint(0)
+            self.L.DSPR_peek_output(self.h, C.byref(n), C.byref(ch), C.byref(sr))
+            if n.value == 0:
+                break
+            buf = np.empty((n.value, ch.value), dtype=np.float32)
+            _check(self.L.DSPR_pop_output(self.h, buf.ctypes.data, n.value), "DSPR_pop_output")
+            chunks.append((buf, sr.value))
+        return chunks
+
+    def on_chunk(self, x, sample_rate, channel_config=3):
+        """Returns (passthrough, [(frames array, sample_rate), ...])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        x = x.reshape(x.shape[0], -1)
+        p = C.c_int(0)
+        _check(self.L.DSPR_on_chunk(self.h, x.ctypes.data, x.shape[0], x.shape[1], sample_rate, channel_config,
+                                    C.byref(p)), "DSPR_on_chunk")
+        return bool(p.value), self._drain_queue()
+
+    def end_of_track(self):
+        _check(self.L.DSPR_end_of_track(self.h), "DSPR_end_of_track")
+        return self._drain_queue()
+
+    def flush(self):
+        self.L.DSPR_flush(self.h)
+
+    @property
+    def latency(self):
+        return self.L.DSPR_get_latency(self.h)

@@ -63,6 +63,25 @@ int RRX_describe_plan(const RR_config *config, char *buf, size_t cap);
  * the full length.  Returns RR_OK or RR_INVPARAM. */
 int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, size_t *count);
 
+/* ---- plugin layer (host side of foo_dsp_rate.cpp, restated over plain buffers) -------------------------
+ * Mirrors class dsp_rate (foo_dsp_rate.h:24-80): chunk staging, LPC extrapolation of the track edges on
+ * the host (lpc/lpc.cpp), pre-roll dropping, latency accounting; the resampling itself goes through RR_*.
+ * out_rate follows RateConfig::outRate (dsp_config.h:60-95): Hz, or -2/-5 (x2/x4), -3/-4 (/2, /4). */
+typedef struct DSPR_handle_tag DSPR_handle;
+int DSPR_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase, DSPR_handle **h);
+void DSPR_destroy(DSPR_handle **h);
+/* dsp_rate::on_chunk (foo_dsp_rate.cpp:130-210): *passthrough = 1 when the chunk needs no resampling and
+ * must be forwarded untouched; otherwise it is consumed and output chunks are queued. Returns RR_error. */
+int DSPR_on_chunk(DSPR_handle *h, const fb_sample_t *data, size_t frames, unsigned channels, unsigned sample_rate,
+                  unsigned channel_config, int *passthrough);
+int DSPR_end_of_track(DSPR_handle *h); /* on_endoftrack / on_endofplayback -> flushwrite, foo_dsp_rate.cpp:80-82,218-313 */
+void DSPR_flush(DSPR_handle *h);       /* dsp_rate::flush, foo_dsp_rate.cpp:212-216 */
+double DSPR_get_latency(const DSPR_handle *h); /* foo_dsp_rate.cpp:315-322 */
+/* Output chunks queued so far (what the plugin hands to insert_chunk): peek the oldest one's shape, then pop
+ * it into `dst` (frames * channels floats). */
+int DSPR_peek_output(const DSPR_handle *h, size_t *frames, unsigned *channels, unsigned *sample_rate);
+int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames);
+
 #ifdef __cplusplus
 }
 #endif

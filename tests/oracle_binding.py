@@ -32,8 +32,8 @@ class OrcDesignCall(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_ROOT, "oracle", "rate_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("rate_oracle.c", "plugin_oracle.c", "rate_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -75,6 +75,29 @@ def lib():
         L.orc_dft_length.argtypes = [C.c_int]
         L.orc_kaiser_beta.argtypes = [C.c_double, C.c_double]
         L.orc_kaiser_beta.restype = C.c_double
+        L.orc_dsp_create.argtypes = [C.c_int] * 5
+        L.orc_dsp_create.restype = C.c_void_p
+        L.orc_dsp_destroy.argtypes = [C.c_void_p]
+        L.orc_dsp_destroy.restype = None
+        L.orc_dsp_on_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+        L.orc_dsp_end_of_track.argtypes = [C.c_void_p]
+        L.orc_dsp_end_of_track.restype = None
+        L.orc_dsp_flush.argtypes = [C.c_void_p]
+        L.orc_dsp_flush.restype = None
+        L.orc_dsp_latency.argtypes = [C.c_void_p]
+        L.orc_dsp_latency.restype = C.c_double
+        L.orc_dsp_out_count.argtypes = [C.c_void_p]
+        L.orc_dsp_out_count.restype = C.c_size_t
+        L.orc_dsp_out_frames.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_dsp_out_frames.restype = C.c_size_t
+        L.orc_dsp_out_channels.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_dsp_out_channels.restype = C.c_uint
+        L.orc_dsp_out_rate.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_dsp_out_rate.restype = C.c_uint
+        L.orc_dsp_out_data.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_dsp_out_data.restype = P(C.c_float)
+        L.orc_dsp_out_clear.argtypes = [C.c_void_p]
+        L.orc_dsp_out_clear.restype = None
         _lib = L
     return _lib
 
@@ -185,6 +208,52 @@ class Oracle:
         arr = (OrcDesignCall * 16)()
         n = min(self.L.orc_design_trace(self.h, arr, 16), 16)
         return [{f[0]: getattr(arr[i], f[0]) for f in OrcDesignCall._fields_} for i in range(n)]
+
+
+class OracleDsp:
+    """CPU restatement of the plugin's dsp_rate object (oracle/plugin_oracle.c); same call shapes as
+    foo_dsp_resampler_amd.DspRate."""
+
+    def __init__(self, out_rate, quality=0, allow_aliasing=0, passband10=950, phase=50):
+        self.L = lib()
+        self.h = self.L.orc_dsp_create(out_rate, quality, allow_aliasing, passband10, phase)
+
+    def close(self):
+        if self.h:
+            self.L.orc_dsp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _take(self):
+        out = []
+        for i in range(self.L.orc_dsp_out_count(self.h)):
+            n, ch = self.L.orc_dsp_out_frames(self.h, i), self.L.orc_dsp_out_channels(self.h, i)
+            p = self.L.orc_dsp_out_data(self.h, i)
+            out.append((np.ctypeslib.as_array(p, (n * ch,)).reshape(n, ch).copy(), self.L.orc_dsp_out_rate(self.h, i)))
+        self.L.orc_dsp_out_clear(self.h)
+        return out
+
+    def on_chunk(self, x, sample_rate, channel_config=3):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        x = x.reshape(x.shape[0], -1)
+        p = self.L.orc_dsp_on_chunk(self.h, x.ctypes.data, x.shape[0], x.shape[1], sample_rate, channel_config)
+        return bool(p), self._take()
+
+    def end_of_track(self):
+        self.L.orc_dsp_end_of_track(self.h)
+        return self._take()
+
+    def flush(self):
+        self.L.orc_dsp_flush(self.h)
+
+    @property
+    def latency(self):
+        return self.L.orc_dsp_latency(self.h)
 
 
 def lcg_noise(n_frames, nch, seed):

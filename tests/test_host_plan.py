@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for h in ("ratelib.h", "ratelib_amd.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        declared |= set(re.findall(r"\b((?:RRX?_|init_|close_)[A-Za-z_]+)\s*\(", txt))
+        declared |= set(re.findall(r"\b((?:RRX?_|DSPR_|init_|close_)[A-Za-z_]+)\s*\(", txt))
     assert declared == set(F.EXPECTED_SYMBOLS), declared ^ set(F.EXPECTED_SYMBOLS)
 
 
