@@ -1,5 +1,6 @@
 // Stream engine. See engine.hpp.
 #include "engine.hpp"
+#include <cstdio>
 
 #include "design.hpp"
 
@@ -90,6 +91,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
 
   dbg_ = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
   no_side_ = getenv("RSMP_NO_SIDE") != nullptr;
+  if (getenv("RSMP_STAMPS")) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stamps_), 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(stamps_, 0, 8 * sizeof(unsigned long long)));
+  }
   const int ns = int(plan_.stages.size());
   book_.wr.assign(ns + 1, 0);
   book_.rd.assign(ns + 1, 0);
@@ -245,6 +250,34 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       if ((rc = upload(tiles.data(), tiles.size() * sizeof(double), &d)) != kOk) return rc;
       fu.cft = static_cast<double *>(d);
     }
+    { // matrix-pipe variant (fused.hip): A operands of v_mfma_f64_4x4x4, lane = 16k + 4b + i holds the
+      // coefficient of residue 16g + 4b + i at tap 4s + k of its 4-residue block's common window
+      int d4 = 0;
+      for (int rb = 0; rb < p.L; rb += 4) {
+        const long long a0 = at0 + (long long)rb * pstep, a1 = at0 + (long long)std::min(rb + 3, p.L - 1) * pstep;
+        d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
+      }
+      const int KS = std::max(7, (p.n + d4 + 3) / 4), NGRP = (p.L + 15) / 16;
+      if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS)) {
+        std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
+        for (int g = 0; g < NGRP; ++g)
+          for (int s = 0; s < KS; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int k = lane >> 4, bq = (lane >> 2) & 3, ii = lane & 3;
+              const int rb = 16 * g + 4 * bq, r = rb + ii;
+              if (r >= p.L) continue;
+              const int qb = (at0 + rb * pstep) / p.L;
+              const int ar = at0 + r * pstep, q = ar / p.L, ph = ar - q * p.L;
+              const int j = 4 * s + k - (q - qb);
+              if (j >= 0 && j < p.n) am[(size_t(g) * KS + s) * 64 + lane] = plan_.poly_table[size_t(ph) * p.n + j];
+            }
+        void *dm = nullptr;
+        if ((rc = upload(am.data(), am.size() * sizeof(double), &dm)) != kOk) return rc;
+        fu.cfm = static_cast<double *>(dm);
+        fu.NGRP = NGRP;
+        fu.KS = KS;
+      }
+    }
     const size_t per_launch = size_t(kFusedMaxBlocks - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
     // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
     double ahead = 1;
@@ -349,10 +382,19 @@ Engine::~Engine()
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
   set_profiling(false);
   if (d_stage_) (void)hipFree(d_stage_);
+  if (stamps_) {
+    unsigned long long h[8] = {};
+    if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7])
+      fprintf(stderr, "RSMP_STAMPS workgroups %llu  avg cycles: load %.0f  fwd %.0f  mul %.0f  inv %.0f  cf+smp %.0f  poly %.0f  total %.0f\n",
+              h[7], double(h[0]) / h[7], double(h[1]) / h[7], double(h[2]) / h[7], double(h[3]) / h[7], double(h[4]) / h[7],
+              double(h[5]) / h[7], double(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / h[7]);
+    (void)hipFree(stamps_);
+  }
   for (Fuse &f : fuse_) {
     if (f.seam) (void)hipFree(f.seam);
     if (f.cft) (void)hipFree(f.cft);
     if (f.perm) (void)hipFree(f.perm);
+    if (f.cfm) (void)hipFree(f.cfm);
   }
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
   if (ev_fused_) (void)hipEventDestroy(ev_fused_);
@@ -591,8 +633,11 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.KC = fu.KC;
           fa.kper = fu.kper;
           fa.perm = fu.perm;
+          fa.cfm = fu.cfm;
+          fa.NGRP = fu.NGRP;
+          fa.KS = fu.KS;
           fa.dbg = dbg_;
-          fa.pf_dist = 0;
+          fa.stamps = stamps_;
           if (pend.nblocks > kFusedMaxBlocks) return kInternal;
           for (int k = 0; k < pend.nblocks; ++k) { // output bookkeeping of each block (closed forms, see fused.hip)
             const long long b0 = fa.b_offset + (pend.B0 + k) * (long long)fa.d.V;

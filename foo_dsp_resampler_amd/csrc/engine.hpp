@@ -109,7 +109,8 @@ private:
   std::vector<DftGpu> dftg_;        // indexed by stage
   std::vector<long long> hist_;     // per fifo: items below rd that must stay readable
   // fused dft->vpoly0 path
-  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0; };
+  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0;
+                double *cfm = nullptr; int NGRP = 0, KS = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   struct Pending { long long B0 = 0; int nblocks = 0; };
   struct ProfRec { hipEvent_t e0, e1; bool hot; };
@@ -119,6 +120,7 @@ private:
   void prof_end(int idx);
   int dbg_ = 0;           // RSMP_DBG ablation bits (0 in production)
   bool no_side_ = false;  // RSMP_NO_SIDE: keep seam kernels on the main stream
+  unsigned long long *stamps_ = nullptr; // RSMP_STAMPS: device buffer of per-phase cycle sums
   float *d_stage_ = nullptr;
   size_t stage_floats_ = 0;
   size_t slab_frames_ = 0;

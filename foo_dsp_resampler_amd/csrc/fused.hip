@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace rsmp {
 
@@ -32,7 +33,10 @@ constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) th
 // XCD and their 2*(taps-1)-sample input overlap is an L2 hit.  (A persistent grid with the coefficient tile
 // kept in registers across items was measured 1.6x SLOWER: at the 256-VGPR cap the FFT passes lose their
 // load/compute overlap.)
-template <int LOG2N, int LOG2P, int G, int SPAN>
+//
+// MF variant (polyphase on the fp64 matrix pipe): see the "polyphase FIR on v_mfma_f64_4x4x4" section below;
+// SPAN then counts k-steps (4 taps each) of a 4-residue block's common window.
+template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>
 __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
   // ------------------------------------------------------------------ per-thread polyphase constants
   // thread -> (residue group m, period chunk kc); residues r0..r0+G-1 (mod polyL)
   const int pl = a.polyL, step = a.step, at0 = (int)a.at0;
-  const int item = a.perm[tid]; // host-chosen lane -> (residue group, period chunk) map, see engine.cpp
+  const int item = MF ? 0 : a.perm[tid]; // host-chosen lane -> (residue group, period chunk) map, see engine.cpp
   const int m = item % a.NG, kc = item / a.NG;
   const bool poly_thread = kc < a.KC;
   const int r0 = G * m;
@@ -60,6 +64,17 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
 #pragma unroll
   for (int g = 0; g < G; ++g) rv[g] = r0 + g < pl;
   const double *__restrict__ cft = a.cft + tid;
+
+  // RSMP_STAMPS instrumentation: wave 0's view of the phase boundaries (s_memtime, shader clock)
+  unsigned long long tstamp = a.stamps ? __builtin_readcyclecounter() : 0;
+#define RSMP_STAMP(slot) \
+  if (a.stamps) { \
+    if (poly_wait) __builtin_amdgcn_s_waitcnt(0); \
+    const unsigned long long now = __builtin_readcyclecounter(); \
+    if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp); \
+    tstamp = now; \
+  }
+  constexpr bool poly_wait = true;
 
   { // one work item per workgroup (see the note above about a persistent loop)
     const int w = blockIdx.x;
@@ -108,8 +123,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       }
     }
 
+    RSMP_STAMP(0)
     // ---------------------------------------------------------------- FFT-FIR (as dft_kernel)
     if (!(a.dbg & 4)) fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
+    RSMP_STAMP(1)
     if constexpr (LOG2P < LOG2N) {
       double2 g[16]; // issued before the exchange so the L2 latency overlaps it
 #pragma unroll
@@ -137,16 +154,20 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
         v[s] = cmul(v[s], c64{g.x, g.y});
       }
     }
+    RSMP_STAMP(2)
     if (!(a.dbg & 2)) fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
+    RSMP_STAMP(3)
 
     // coefficient tile of this thread: rows of its G phases shifted to a common window start and zero
     // padded, pre-arranged by the host as [tap][g][thread] (coalesced, branch-free); issued here so the
     // L2 latency overlaps the LDS writes below
-    double cf[G][SPAN];
+    double cf[G][MF ? 1 : SPAN];
+    if constexpr (!MF) {
 #pragma unroll
-    for (int mm = 0; mm < SPAN; ++mm)
+      for (int mm = 0; mm < SPAN; ++mm)
 #pragma unroll
-      for (int g = 0; g < G; ++g) cf[g][mm] = cft[(mm * G + g) * T];
+        for (int g = 0; g < G; ++g) cf[g][mm] = cft[(mm * G + g) * T];
+    }
 
     // ---------------------------------------------------------------- stage-1 samples -> LDS
     // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
@@ -175,9 +196,121 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       }
     }
     __syncthreads();
+    RSMP_STAMP(4)
 
-    // ---------------------------------------------------------------- polyphase FIR from LDS
+    // ---------------------------------------------------------------- polyphase FIR on v_mfma_f64_4x4x4
+    // out[r, q, ch] = sum_t c[r][t] * x[ch][w(r) + step*q + t]  (r = output residue mod L, q = period):
+    // for a block of 4 consecutive residues the windows start within 3 samples of each other, so with
+    // the rows shifted to the block's common start (zero padded to 4*SPAN taps) this is a product
+    // A[4 residues x 4 taps] * B[4 taps x 4 periods], accumulated over SPAN k-steps, once per channel.
+    // One instruction carries 4 such blocks (16 residues): lane maps measured on gfx950
+    // (tools/probe_mfma4.hip): A lane = 16k + 4b + i, B lane = 16k + 4b + j, D lane = 16i + 4b + j.
+    // A lane's B operands for both channels are ONE ds_read_b128 of the (A,B)-interleaved LDS samples, feeding
+    // two independent accumulation chains (so dependent-MFMA wait states are filled), i.e. 16 bytes of LDS per
+    // 8 useful-or-padded FMAs per lane instead of per 4 in the vector version; a lane ends up with both
+    // channels of one output frame -> one 8-byte store.  Taps are summed in ascending order like the
+    // reference's loop.  The fp64 matrix and vector pipes share hardware (tools/ubench_mfma.hip), so the
+    // gain is LDS traffic, issue slots and registers, not peak flops.
     const FusedBlock fb = a.blk[bl];
+    if constexpr (MF) {
+      if (!(a.dbg & 1) && fb.cnt > 0) {
+        constexpr int NW = T / 64;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int hi = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+        const int irel_hi = fb.irel_lo + fb.cnt;
+        const int ncs = (fb.K + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
+
+        bool ofast = false;
+        float *obase = nullptr; // frame i_lo's first float of this pair
+        int ofs = 2;            // floats between consecutive frames
+        {
+          const long long o0 = a.out_offset2 + fb.i_lo, o1 = o0 + fb.cnt;
+          if (out.is_f32 && hasb && !(out.f.nch & 1)) {
+            const int hp = out.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+            ofs = out.f.nch;
+            if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
+              obase = out.f.ext + strm * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * out.f.nch + 2 * pin;
+              ofast = true;
+            } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
+                       (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
+              obase = out.f.ring + strm * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * out.f.nch + 2 * pin;
+              ofast = true;
+            }
+            ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
+          }
+        }
+        const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+        const int li_max = V + kPad - 4 * SPAN;
+
+        // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
+        double cn_[SPAN];
+        {
+          const double *cp = a.cfm + (size_t)(wave >> 1) * SPAN * 64 + lane;
+#pragma unroll
+          for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
+        }
+        for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
+          const int g = it >> 1, second = (it + (it >> 2)) & 1; // halves alternate so the waves stay balanced
+          int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
+          // column steps whose 64 outputs all lie outside [irel_lo, irel_hi) (block edges) are skipped
+          while (cs0 < cs1 && (4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
+          while (cs1 > cs0 && 4 * (cs1 - 1) * pl + 16 * g >= irel_hi) --cs1;
+          double ca_[SPAN];
+#pragma unroll
+          for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
+          if (it + NW < 2 * a.NGRP) {
+            const double *cp = a.cfm + (size_t)((it + NW) >> 1) * SPAN * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
+          }
+          int rb = 16 * g + 4 * bq;
+          if (rb >= pl) rb = 0; // idle block: all-zero coefficients, any in-range window will do
+          const int qb = (at0 + rb * step) / pl + fb.base_li + hi;
+          const int rD = 16 * g + 4 * bq + hi;
+          // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
+          // step's reads are issued before this step's MFMA chains so their latency hides behind them
+          auto win = [&](int cs) {
+            const int li = max(-kPad, min(li_max, qb + min(4 * cs + jq, fb.K - 1) * step));
+            return smp + li;
+          };
+          double2 xb[SPAN], xn[SPAN];
+          if (cs0 < cs1) {
+            const double2 *xp = win(cs0);
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) xn[s] = xp[4 * s];
+          }
+          for (int cs = cs0; cs < cs1; ++cs) {
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) xb[s] = xn[s];
+            if (cs + 1 < cs1) {
+              const double2 *xp = win(cs + 1);
+#pragma unroll
+              for (int s = 0; s < SPAN; ++s) xn[s] = xp[4 * s];
+            }
+            double accA = 0.0, accB = 0.0;
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) {
+              accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], xb[s].x, accA, 0, 0, 0);
+              accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], xb[s].y, accB, 0, 0, 0);
+            }
+            if (a.dbg & 16) { if (accA == 12345.678) lds[0] = accA + accB; continue; }
+            const int kr = 4 * cs + jq;
+            const int ib = kr * pl + rD;
+            if (kr < fb.K && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
+              const int orel = ib - fb.irel_lo;
+              if (ofast) {
+                *reinterpret_cast<float2 *>(obase + (long long)orel * ofs) = make_float2((float)accA, (float)accB);
+              } else {
+                const long long oabs = a.out_offset2 + fb.i_lo + orel;
+                fifo_put(oa, oabs, accA);
+                if (hasb) fifo_put(ob, oabs, accB);
+              }
+            }
+          }
+        }
+      }
+    } else
+    // ---------------------------------------------------------------- polyphase FIR from LDS (vector pipe)
     if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
       const int irel_hi = fb.irel_lo + fb.cnt;
       const int kper = a.kper; // fixed chunk length (not per block) so that the lane map's bank pattern is static
@@ -250,7 +383,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
         }
       }
     }
+    RSMP_STAMP(5)
+    if (a.stamps && tid == 0) atomicAdd(a.stamps + 7, 1ull);
   }
+#undef RSMP_STAMP
 }
 
 // Outputs whose window straddles the boundary between block B-1 and block B (or precedes block 0):
@@ -284,21 +420,22 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
   }
 }
 
-template <int LOG2N, int LOG2P, int G, int SPAN>
+template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>
 static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const FusedArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
+  static const size_t lds_pad = getenv("RSMP_LDS_PAD") ? size_t(atoi(getenv("RSMP_LDS_PAD"))) : 0; // occupancy experiments
+  const size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N)) + lds_pad;
   static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
   if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
   }
   const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
   dim3 grid(nitems), block(N / 16);
-  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN>), grid, block, lds_bytes, st, in, out, a);
+  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), grid, block, lds_bytes, st, in, out, a);
   return hipGetLastError();
 }
 
@@ -310,6 +447,11 @@ hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const
   return hipGetLastError();
 }
 
+bool fused_mfma_supported(int log2n, int log2p, int ksteps)
+{
+  return log2n == 12 && (log2p == 11 || log2p == 12) && (ksteps == 7 || ksteps == 8);
+}
+
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs)
 {
   if (log2n < 11 || log2n > 13) return false;
@@ -318,14 +460,20 @@ bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_o
 }
 
 #define RSMP_FUSED_CASE(n, p) \
-  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2, kSpanMax>(in, out, a, st);
+  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2, kSpanMax, false>(in, out, a, st);
 #define RSMP_FUSED_EXACT(n, p, sp) \
-  if (log2n == n && log2p == p && a.span == sp) return launch_fused_t<n, p, 2, sp>(in, out, a, st);
+  if (log2n == n && log2p == p && a.span == sp) return launch_fused_t<n, p, 2, sp, false>(in, out, a, st);
+#define RSMP_FUSED_MF(n, p, ks) \
+  if (log2n == n && log2p == p && a.KS == ks) return launch_fused_t<n, p, 2, ks, true>(in, out, a, st);
 
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
                         const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
+  if (a.cfm) { // polyphase on the matrix pipe
+    RSMP_FUSED_MF(12, 11, 7) RSMP_FUSED_MF(12, 12, 7) RSMP_FUSED_MF(12, 11, 8) RSMP_FUSED_MF(12, 12, 8)
+    return hipErrorInvalidValue;
+  }
   // exact-window variants for the chains the plugin's rate matrix produces at Best (24 taps/phase)
   RSMP_FUSED_EXACT(12, 11, 25) RSMP_FUSED_EXACT(12, 11, 26) RSMP_FUSED_EXACT(12, 12, 26) RSMP_FUSED_EXACT(12, 12, 27)
   // generic variants: window padded to kSpanMax

@@ -75,8 +75,10 @@ struct FusedArgs {
   int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
   int kper;              // periods per chunk
   const int *perm;       // [threads] lane -> item (kc * NG + m), chosen so LDS window reads avoid bank conflicts
+  const double *cfm;     // matrix-pipe variant: A operands [16-residue group][k-step][lane]; null = vector variant
+  int NGRP, KS;          // 16-residue groups, k-steps (4 taps each) of a 4-residue block's common window
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
-  int pf_dist;           // reserved (0)
+  unsigned long long *stamps; // RSMP_STAMPS: per-phase cycle sums [8] (null in production)
   FusedBlock blk[kFusedMaxBlocks];
 };
 
@@ -109,6 +111,7 @@ hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const 
 // seam_kernel: the outputs whose window straddles two blocks; launch after launch_fused on the same stream
 hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
+bool fused_mfma_supported(int log2n, int log2p, int ksteps);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
 hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
