@@ -258,7 +258,12 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
       }
       const int KS = std::max(7, (p.n + d4 + 3) / 4), NGRP = (p.L + 15) / 16;
-      if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS)) {
+      // window starts of the 4-residue blocks span [qb_min, qb_max]; the two-round sample image of the kernel
+      // needs every period to fit one of the rounds (fused.hip, kSA / kSB0)
+      int qb_min = at0 / p.L, qb_max = qb_min;
+      for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
+      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= 256 + 32;
+      if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)
           for (int s = 0; s < KS; ++s)
@@ -276,6 +281,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         fu.cfm = static_cast<double *>(dm);
         fu.NGRP = NGRP;
         fu.KS = KS;
+        fu.qb_max = qb_max;
       }
     }
     const size_t per_launch = size_t(kFusedMaxBlocks - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
@@ -650,6 +656,11 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
             fb.irel_lo = int(ilo - kk_lo * sp.L);
             fb.base_li = int(kk_lo * step - b0);
             fb.K = fb.cnt > 0 ? int((ihi - 1) / sp.L - kk_lo) + 1 : 0;
+            fb.KA = fb.K;
+            if (fu.cfm && fa.d.V > 12 * 256) { // periods whose (padded) windows end inside the first LDS image
+              const int a_hi = 12 * 256 + 32 - 4 * fu.KS - 3, num = a_hi - fb.base_li - fu.qb_max;
+              fb.KA = std::max(0, std::min(fb.K, num < 0 ? 0 : num / int(step) + 1));
+            }
             if (fb.K > fu.KC * fu.kper) return kInternal;
           }
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i

@@ -126,14 +126,56 @@ constexpr int fft_lds_doubles(int log2m)
   const int m = 1 << log2m, r0 = (log2m & 3) ? (1 << (log2m & 3)) : 16;
   return 2 * (r0 >= 8 ? m + m / r0 : m);
 }
+// same for the two-half-rounds exchange (MODE 2)
+constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) / 2; }
 
 // Exchange the 16 register values through LDS: value in slot s goes to Stockham position pos[s];
 // afterwards slot s holds element tid + s*T.  All threads of the workgroup must call this
 // (barriers); only `active` threads move data.
-template <int T, bool SPLIT, int PADR = 1>
+//
+// MODE 0: one round of 16-byte elements (M*16 bytes of LDS, plus padding).
+// MODE 1 ("split"): real and imaginary halves in two rounds of 8-byte elements (M*8 bytes).
+// MODE 2 ("halves"): destinations [0, M/2) first, then [M/2, M), 16-byte elements both times (M*8 bytes plus
+//         padding): same LDS traffic as mode 0, two more barriers, half the footprint.
+template <int T, int MODE, int PADR = 1>
 __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16], int tid, bool active, double *lds)
 {
-  if (!SPLIT) {
+  if (MODE == 2) {
+    // a thread's 16 values may all belong to the second round, so the first round's reads need their own
+    // registers until the second round's writes are out
+    constexpr int H = 8 * T; // M / 2
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    c64 lo[8];
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (pos[s] < H) l2[lds_phys<PADR>(pos[s])] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        double2 q = l2[lds_phys<PADR>(tid + s * T)];
+        lo[s] = {q.x, q.y};
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (pos[s] >= H) l2[lds_phys<PADR>(pos[s] - H)] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        double2 q = l2[lds_phys<PADR>(tid + s * T)];
+        v[s + 8] = {q.x, q.y};
+        v[s] = lo[s];
+      }
+    }
+    __syncthreads();
+  } else if (MODE == 0) {
     double2 *l2 = reinterpret_cast<double2 *>(lds);
     if (active) {
 #pragma unroll
@@ -172,7 +214,7 @@ __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16],
   }
 }
 
-template <int LOG2M, int R, int NS, int DIR, bool SPLIT, bool LAST>
+template <int LOG2M, int R, int NS, int DIR, int MODE, bool LAST>
 __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int T = (1 << LOG2M) / 16, NB = 16 / R;
@@ -203,19 +245,19 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
       for (int r = 0; r < R; ++r) pos[t + NB * r] = (j - k) * R + k + r * NS;
     }
-    lds_exchange<T, SPLIT, (NS == 1 && !SPLIT) ? R : 1>(v, pos, tid, active, lds);
+    lds_exchange<T, MODE, (NS == 1 && MODE != 1) ? R : 1>(v, pos, tid, active, lds);
   }
 }
 
 // Full transform.  `tw` points at this size's table (fft_twiddle_count(LOG2M) entries).
-template <int LOG2M, int DIR, bool SPLIT>
+template <int LOG2M, int DIR, int MODE>
 __device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int R0 = fft_first_radix(LOG2M), NP = fft_num_passes(LOG2M);
-  fft_pass<LOG2M, R0, 1, DIR, SPLIT, NP == 1>(v, tid, active, tw, lds);
-  if constexpr (NP >= 2) fft_pass<LOG2M, 16, R0, DIR, SPLIT, NP == 2>(v, tid, active, tw, lds);
-  if constexpr (NP >= 3) fft_pass<LOG2M, 16, R0 * 16, DIR, SPLIT, NP == 3>(v, tid, active, tw + 15 * R0, lds);
-  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, SPLIT, NP == 4>(v, tid, active, tw + 15 * R0 * 17, lds);
+  fft_pass<LOG2M, R0, 1, DIR, MODE, NP == 1>(v, tid, active, tw, lds);
+  if constexpr (NP >= 2) fft_pass<LOG2M, 16, R0, DIR, MODE, NP == 2>(v, tid, active, tw, lds);
+  if constexpr (NP >= 3) fft_pass<LOG2M, 16, R0 * 16, DIR, MODE, NP == 3>(v, tid, active, tw + 15 * R0, lds);
+  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4>(v, tid, active, tw + 15 * R0 * 17, lds);
 }
 
 } // namespace rsmp

@@ -17,13 +17,18 @@
 #include "fifo_device.hpp"
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstdio>
 
 namespace rsmp {
 
 constexpr int kPad = 32;      // LDS guard samples around each channel's block
-constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) the register tile supports
+constexpr int kSpanMax = 32;
+// matrix-pipe variant (N = 4096): LDS holds the block's samples in two rounds so that three workgroups fit a CU:
+// round A = register slots [0, kSA) i.e. samples [0, 256*kSA) plus kPad more, round B = slots [kSB0, 16)
+constexpr int kSA = 12, kSB0 = 11;  // largest window length (taps + offset spread) the register tile supports
 
 // SPAN = window length of a G-tile (compile time, so the whole tap loop is straight-line code and the LDS
 // reads are issued ahead of the FMAs); a.span <= SPAN, coefficients beyond a.span are zero.
@@ -37,7 +42,7 @@ constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) th
 // MF variant (polyphase on the fp64 matrix pipe): see the "polyphase FIR on v_mfma_f64_4x4x4" section below;
 // SPAN then counts k-steps (4 taps each) of a 4-residue block's common window.
 template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>
-__global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
+__global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
   constexpr int T = N / 16, TF = P / 16;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
 
     RSMP_STAMP(0)
     // ---------------------------------------------------------------- FFT-FIR (as dft_kernel)
-    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, false>(v, tid, fwd_active, a.d.tw_fwd, lds);
+    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
     RSMP_STAMP(1)
     if constexpr (LOG2P < LOG2N) {
       double2 g[16]; // issued before the exchange so the L2 latency overlaps it
@@ -155,7 +160,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       }
     }
     RSMP_STAMP(2)
-    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, false>(v, tid, true, a.d.tw_inv, lds);
+    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, MF ? 2 : 0>(v, tid, true, a.d.tw_inv, lds);
     RSMP_STAMP(3)
 
     // coefficient tile of this thread: rows of its G phases shifted to a common window start and zero
@@ -179,7 +184,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       for (int s = 0; s < 16; ++s) {
         const int n = tid + s * T;
         if (n < V) {
-          smp[n] = make_double2(v[s].x, v[s].y);
+          // matrix-pipe variant: round A holds samples [0, kSA*T + kPad) only (see below)
+          if (!MF || s < kSA || (s == kSA && tid < kPad)) smp[n] = make_double2(v[s].x, v[s].y);
           if (n < nm1) {
             seamA[n] = v[s].x;
             if (hasb) seamB[n] = v[s].y;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
       }
       if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
         smp[tid - kPad] = make_double2(0.0, 0.0);
-        smp[V + tid] = make_double2(0.0, 0.0);
+        if (!MF || V < kSA * T + kPad) smp[V + tid] = make_double2(0.0, 0.0);
       }
     }
     __syncthreads();
@@ -213,53 +219,56 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
     // gain is LDS traffic, issue slots and registers, not peak flops.
     const FusedBlock fb = a.blk[bl];
     if constexpr (MF) {
-      if (!(a.dbg & 1) && fb.cnt > 0) {
-        constexpr int NW = T / 64;
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int hi = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-        const int irel_hi = fb.irel_lo + fb.cnt;
-        const int ncs = (fb.K + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
+      constexpr int NW = T / 64;
+      const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int hi = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+      const int irel_hi = fb.irel_lo + fb.cnt;
+      const bool run = !(a.dbg & 1) && fb.cnt > 0;
 
-        bool ofast = false;
-        float *obase = nullptr; // frame i_lo's first float of this pair
-        int ofs = 2;            // floats between consecutive frames
-        {
-          const long long o0 = a.out_offset2 + fb.i_lo, o1 = o0 + fb.cnt;
-          if (out.is_f32 && hasb && !(out.f.nch & 1)) {
-            const int hp = out.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
-            ofs = out.f.nch;
-            if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
-              obase = out.f.ext + strm * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * out.f.nch + 2 * pin;
-              ofast = true;
-            } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
-                       (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
-              obase = out.f.ring + strm * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * out.f.nch + 2 * pin;
-              ofast = true;
-            }
-            ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
+      bool ofast = false;
+      float *obase = nullptr; // frame i_lo's first float of this pair
+      int ofs = 2;            // floats between consecutive frames
+      {
+        const long long o0 = a.out_offset2 + fb.i_lo, o1 = o0 + fb.cnt;
+        if (out.is_f32 && hasb && !(out.f.nch & 1)) {
+          const int hp = out.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+          ofs = out.f.nch;
+          if (out.f.ext && o0 >= out.f.ext_begin && o1 <= out.f.ext_end) {
+            obase = out.f.ext + strm * out.f.ext_stream_stride + (o0 - out.f.ext_begin) * out.f.nch + 2 * pin;
+            ofast = true;
+          } else if ((!out.f.ext || o0 >= out.f.ext_end || o1 <= out.f.ext_begin) &&
+                     (o0 & out.f.ring_mask) + (o1 - o0) <= out.f.ring_mask + 1) {
+            obase = out.f.ring + strm * out.f.ring_stream_stride + (o0 & out.f.ring_mask) * out.f.nch + 2 * pin;
+            ofast = true;
           }
+          ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
         }
-        const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
-        const int li_max = V + kPad - 4 * SPAN;
+      }
+      const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
 
-        // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
-        double cn_[SPAN];
-        {
-          const double *cp = a.cfm + (size_t)(wave >> 1) * SPAN * 64 + lane;
+      // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
+      double cn_[SPAN];
+      {
+        const double *cp = a.cfm + (size_t)(wave >> 1) * SPAN * 64 + lane;
 #pragma unroll
-          for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
-        }
+        for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
+      }
+      // periods [kb, ke) of the block from the LDS image `xs` whose element 0 is sample n0; li_lo/li_hi clamp
+      // the window start of outputs that are not stored anyway (block edges) into the image
+      auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
+        const int ncs = (ke - kb + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
         for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
           const int g = it >> 1, second = (it + (it >> 2)) & 1; // halves alternate so the waves stay balanced
           int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
           // column steps whose 64 outputs all lie outside [irel_lo, irel_hi) (block edges) are skipped
-          while (cs0 < cs1 && (4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
-          while (cs1 > cs0 && 4 * (cs1 - 1) * pl + 16 * g >= irel_hi) --cs1;
+          while (cs0 < cs1 && (kb + 4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
+          while (cs1 > cs0 && (kb + 4 * (cs1 - 1)) * pl + 16 * g >= irel_hi) --cs1;
           double ca_[SPAN];
 #pragma unroll
           for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
-          if (it + NW < 2 * a.NGRP) {
-            const double *cp = a.cfm + (size_t)((it + NW) >> 1) * SPAN * 64 + lane;
+          {
+            const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
+            const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
           }
@@ -270,8 +279,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
           // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
           // step's reads are issued before this step's MFMA chains so their latency hides behind them
           auto win = [&](int cs) {
-            const int li = max(-kPad, min(li_max, qb + min(4 * cs + jq, fb.K - 1) * step));
-            return smp + li;
+            const int li = max(li_lo, min(li_hi, qb + min(kb + 4 * cs + jq, ke - 1) * step));
+            return xs + li;
           };
           double2 xb[SPAN], xn[SPAN];
           if (cs0 < cs1) {
@@ -294,9 +303,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
               accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], xb[s].y, accB, 0, 0, 0);
             }
             if (a.dbg & 16) { if (accA == 12345.678) lds[0] = accA + accB; continue; }
-            const int kr = 4 * cs + jq;
+            const int kr = kb + 4 * cs + jq;
             const int ib = kr * pl + rD;
-            if (kr < fb.K && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
+            if (kr < ke && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
               const int orel = ib - fb.irel_lo;
               if (ofast) {
                 *reinterpret_cast<float2 *>(obase + (long long)orel * ofs) = make_float2((float)accA, (float)accB);
@@ -308,7 +317,23 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 2) void fused_kernel(AnyView in,
             }
           }
         }
+      };
+      // round A: periods whose windows end inside the samples written above
+      if (run && !(a.dbg & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
+      __syncthreads();
+      // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
+      {
+        double2 *l2 = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+        for (int s = kSB0; s < 16; ++s) {
+          const int n = tid + s * T;
+          if (n < V) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
+        }
+        if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
       }
+      __syncthreads();
+      if (run && fb.KA < fb.K && !(a.dbg & 32))
+        poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * SPAN);
     } else
     // ---------------------------------------------------------------- polyphase FIR from LDS (vector pipe)
     if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
@@ -425,13 +450,24 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
 {
   constexpr int N = 1 << LOG2N;
   static const size_t lds_pad = getenv("RSMP_LDS_PAD") ? size_t(atoi(getenv("RSMP_LDS_PAD"))) : 0; // occupancy experiments
-  const size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N)) + lds_pad;
+  size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
+  if (MF) { // half-round exchanges for 4096-point transforms, two-round sample image (fused_kernel, MF part)
+    lds_bytes = 8 * size_t(fft_lds_doubles_halves(LOG2N));
+    if (LOG2P < LOG2N) lds_bytes = std::max(lds_bytes, 8 * size_t(fft_lds_doubles(LOG2P)));
+    lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
+  }
+  lds_bytes += lds_pad;
   static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
   if (!attr_done.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
+    if (getenv("RSMP_OCC")) {
+      int nb = -1;
+      hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), N / 16, lds_bytes);
+      fprintf(stderr, "RSMP_OCC lds %zu blocks/CU %d (%s)\n", lds_bytes, nb, hipGetErrorString(eo));
+    }
   }
   const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
   dim3 grid(nitems), block(N / 16);

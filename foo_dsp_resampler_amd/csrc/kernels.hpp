@@ -57,6 +57,7 @@ struct FusedBlock {
   int irel_lo;    // i_lo - kk_lo * polyL, kk_lo = i_lo / polyL (first period touched)
   int base_li;    // kk_lo * step - b0: window start of (period kk_lo, residue r) is qr(r) + base_li
   int K;          // periods touched by [i_lo, i_lo + cnt)
+  int KA;         // matrix-pipe variant: periods [0, KA) are computed from the first LDS image, the rest from the second
 };
 constexpr int kFusedMaxBlocks = 64;
 
