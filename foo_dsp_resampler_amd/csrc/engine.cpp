@@ -262,7 +262,8 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       // needs every period to fit one of the rounds (fused.hip, kSA / kSB0)
       int qb_min = at0 / p.L, qb_max = qb_min;
       for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
-      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= 256 + 32;
+      // ... and at most 32 periods per block (4 column steps per item), enough phases to fill 16-row tiles
+      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= 256 + 32 && Kmax <= 32 && p.L >= 64;
       if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)

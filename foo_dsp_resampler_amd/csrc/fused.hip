@@ -253,7 +253,34 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
 #pragma unroll
         for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
       }
-      // periods [kb, ke) of the block from the LDS image `xs` whose element 0 is sample n0; li_lo/li_hi clamp
+      // Outputs of an item are stored at the start of the NEXT item, after that item's wait for its A tile:
+      // on gfx950 loads and stores share one in-order counter (vmcnt), so a store issued just before the
+      // wait would put a full store round trip into it.
+      constexpr int MAXCS = 4; // column steps per item (host: at most 32 periods per block)
+      double pA[MAXCS], pB[MAXCS];
+      int pend_n = 0, pend_g = 0, pend_cs0 = 0, pend_kb = 0, pend_ke = 0;
+      auto flush = [&]() {
+#pragma unroll
+        for (int u = 0; u < MAXCS; ++u) {
+          if (u < pend_n) {
+            const int kr = pend_kb + 4 * (pend_cs0 + u) + jq;
+            const int rD = 16 * pend_g + 4 * bq + hi;
+            const int ib = kr * pl + rD;
+            if (kr < pend_ke && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
+              const int orel = ib - fb.irel_lo;
+              if (ofast) {
+                *reinterpret_cast<float2 *>(obase + (long long)orel * ofs) = make_float2((float)pA[u], (float)pB[u]);
+              } else {
+                const long long oabs = a.out_offset2 + fb.i_lo + orel;
+                fifo_put(oa, oabs, pA[u]);
+                if (hasb) fifo_put(ob, oabs, pB[u]);
+              }
+            }
+          }
+        }
+        pend_n = 0;
+      };
+      // periods [kb, ke) of the block from the LDS image `xs` (indexed by sample number); li_lo/li_hi clamp
       // the window start of outputs that are not stored anyway (block edges) into the image
       auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
         const int ncs = (ke - kb + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
@@ -266,6 +293,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
           double ca_[SPAN];
 #pragma unroll
           for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
+          flush();
           {
             const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
             const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
@@ -275,47 +303,38 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
           int rb = 16 * g + 4 * bq;
           if (rb >= pl) rb = 0; // idle block: all-zero coefficients, any in-range window will do
           const int qb = (at0 + rb * step) / pl + fb.base_li + hi;
-          const int rD = 16 * g + 4 * bq + hi;
           // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
-          // step's reads are issued before this step's MFMA chains so their latency hides behind them
-          auto win = [&](int cs) {
+          // step's reads are issued before this step's MFMA chains so their latency hides behind them, into
+          // the other of two register images (no copies)
+          double2 x0[SPAN], x1[SPAN];
+          auto fill = [&](double2 (&x)[SPAN], int cs) {
             const int li = max(li_lo, min(li_hi, qb + min(kb + 4 * cs + jq, ke - 1) * step));
-            return xs + li;
+            const double2 *xp = xs + li;
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) x[s] = xp[4 * s];
           };
-          double2 xb[SPAN], xn[SPAN];
-          if (cs0 < cs1) {
-            const double2 *xp = win(cs0);
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) xn[s] = xp[4 * s];
-          }
-          for (int cs = cs0; cs < cs1; ++cs) {
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) xb[s] = xn[s];
-            if (cs + 1 < cs1) {
-              const double2 *xp = win(cs + 1);
-#pragma unroll
-              for (int s = 0; s < SPAN; ++s) xn[s] = xp[4 * s];
-            }
-            double accA = 0.0, accB = 0.0;
+          auto column_step = [&](const double2 (&x)[SPAN], double &accA, double &accB) {
+            accA = 0.0;
+            accB = 0.0;
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) {
-              accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], xb[s].x, accA, 0, 0, 0);
-              accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], xb[s].y, accB, 0, 0, 0);
+              accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].x, accA, 0, 0, 0);
+              accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].y, accB, 0, 0, 0);
             }
-            if (a.dbg & 16) { if (accA == 12345.678) lds[0] = accA + accB; continue; }
-            const int kr = kb + 4 * cs + jq;
-            const int ib = kr * pl + rD;
-            if (kr < ke && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
-              const int orel = ib - fb.irel_lo;
-              if (ofast) {
-                *reinterpret_cast<float2 *>(obase + (long long)orel * ofs) = make_float2((float)accA, (float)accB);
-              } else {
-                const long long oabs = a.out_offset2 + fb.i_lo + orel;
-                fifo_put(oa, oabs, accA);
-                if (hasb) fifo_put(ob, oabs, accB);
-              }
+          };
+          if (cs0 < cs1) fill(x0, cs0);
+#pragma unroll
+          for (int u = 0; u < MAXCS; ++u) {
+            if (cs0 + u < cs1) {
+              if (cs0 + u + 1 < cs1) fill((u & 1) ? x0 : x1, cs0 + u + 1);
+              column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
             }
           }
+          pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
+          pend_g = g;
+          pend_cs0 = cs0;
+          pend_kb = kb;
+          pend_ke = ke;
         }
       };
       // round A: periods whose windows end inside the samples written above
@@ -334,6 +353,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
       __syncthreads();
       if (run && fb.KA < fb.K && !(a.dbg & 32))
         poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * SPAN);
+      flush();
     } else
     // ---------------------------------------------------------------- polyphase FIR from LDS (vector pipe)
     if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
