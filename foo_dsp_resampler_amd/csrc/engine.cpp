@@ -179,7 +179,12 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     fu.span = p.n + dmax;
     fu.NG = NG;
     fu.KC = threads / NG;
-    fu.slots = 128; // two launches worth: seam(k) still reads its slots while fused(k+1) fills the next ones
+    // blocks per launch: as many as a seam ring of at most 320 MB allows (two launches worth of slots: seam(k) still
+    // reads its slots while fused(k+1) fills the next ones)
+    fu.blk_cap = 64;
+    while (fu.blk_cap < kFusedMaxBlocks && size_t(C_ + 1) * size_t(4 * fu.blk_cap) * 512 <= (size_t(320) << 20)) fu.blk_cap *= 2;
+    fu.slots = 2 * fu.blk_cap;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.blk_dev), size_t(fu.blk_cap) * sizeof(FusedBlock)));
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.seam), bytes));
     HIP_TRY(hipMemset(fu.seam, 0, bytes));
@@ -285,7 +290,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         fu.qb_max = qb_max;
       }
     }
-    const size_t per_launch = size_t(kFusedMaxBlocks - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
+    const size_t per_launch = size_t(fu.blk_cap - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
     // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
     double ahead = 1;
     for (int k = 0; k < i; ++k) ahead *= plan_.stages[k].kind == StageKind::Half ? 0.5 : plan_.stages[k].out_in_ratio;
@@ -392,9 +397,9 @@ Engine::~Engine()
   if (stamps_) {
     unsigned long long h[8] = {};
     if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7])
-      fprintf(stderr, "RSMP_STAMPS workgroups %llu  avg cycles: load %.0f  fwd %.0f  mul %.0f  inv %.0f  cf+smp %.0f  poly %.0f  total %.0f\n",
+      fprintf(stderr, "RSMP_STAMPS workgroups %llu  avg cycles: load %.0f  fwd %.0f  mul %.0f  inv %.0f  cf+smp %.0f  polyA %.0f  poly(B) %.0f  total %.0f\n",
               h[7], double(h[0]) / h[7], double(h[1]) / h[7], double(h[2]) / h[7], double(h[3]) / h[7], double(h[4]) / h[7],
-              double(h[5]) / h[7], double(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / h[7]);
+              double(h[6]) / h[7], double(h[5]) / h[7], double(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]) / h[7]);
     (void)hipFree(stamps_);
   }
   for (Fuse &f : fuse_) {
@@ -402,6 +407,7 @@ Engine::~Engine()
     if (f.cft) (void)hipFree(f.cft);
     if (f.perm) (void)hipFree(f.perm);
     if (f.cfm) (void)hipFree(f.cfm);
+    if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
   if (ev_fused_) (void)hipEventDestroy(ev_fused_);
@@ -645,25 +651,23 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.KS = fu.KS;
           fa.dbg = dbg_;
           fa.stamps = stamps_;
-          if (pend.nblocks > kFusedMaxBlocks) return kInternal;
-          for (int k = 0; k < pend.nblocks; ++k) { // output bookkeeping of each block (closed forms, see fused.hip)
-            const long long b0 = fa.b_offset + (pend.B0 + k) * (long long)fa.d.V;
-            const long long nlo = b0 * sp.L - fa.at0, nhi = (b0 + fa.d.V - sp.n + 1) * sp.L - fa.at0;
-            const long long ilo = nlo <= 0 ? 0 : (nlo + step - 1) / step, ihi = nhi <= 0 ? 0 : (nhi + step - 1) / step;
-            FusedBlock &fb = fa.blk[k];
-            fb.i_lo = ilo;
-            fb.cnt = int(std::max<long long>(0, ihi - ilo));
-            const long long kk_lo = ilo / sp.L;
-            fb.irel_lo = int(ilo - kk_lo * sp.L);
-            fb.base_li = int(kk_lo * step - b0);
-            fb.K = fb.cnt > 0 ? int((ihi - 1) / sp.L - kk_lo) + 1 : 0;
-            fb.KA = fb.K;
-            if (fu.cfm && fa.d.V > 12 * 256) { // periods whose (padded) windows end inside the first LDS image
-              const int a_hi = 12 * 256 + 32 - 4 * fu.KS - 3, num = a_hi - fb.base_li - fu.qb_max;
-              fb.KA = std::max(0, std::min(fb.K, num < 0 ? 0 : num / int(step) + 1));
-            }
-            if (fb.K > fu.KC * fu.kper) return kInternal;
-          }
+          if (pend.nblocks > fu.blk_cap) return kInternal;
+          FusedPrepArgs pa; // output bookkeeping of each block (closed forms in kernels.hpp), evaluated on the device
+          pa.b_offset = fa.b_offset;
+          pa.B0 = pend.B0;
+          pa.at0 = fa.at0;
+          pa.V = fa.d.V;
+          pa.polyL = sp.L;
+          pa.step = int(step);
+          pa.n = sp.n;
+          pa.nblocks = pend.nblocks;
+          pa.two_round = fu.cfm != nullptr;
+          pa.KS = fu.KS;
+          pa.qb_max = fu.qb_max;
+          for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
+            if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
+          HIP_TRY(launch_fused_prep(pa, fu.blk_dev, stream_));
+          fa.blk = fu.blk_dev;
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;

@@ -110,7 +110,8 @@ private:
   std::vector<long long> hist_;     // per fifo: items below rd that must stay readable
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0;
-                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0; };
+                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0;
+                FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   struct Pending { long long B0 = 0; int nblocks = 0; };
   struct ProfRec { hipEvent_t e0, e1; bool hot; };

@@ -74,12 +74,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
   unsigned long long tstamp = a.stamps ? __builtin_readcyclecounter() : 0;
 #define RSMP_STAMP(slot) \
   if (a.stamps) { \
-    if (poly_wait) __builtin_amdgcn_s_waitcnt(0); \
+    if (a.dbg & 256) __builtin_amdgcn_s_waitcnt(0); \
     const unsigned long long now = __builtin_readcyclecounter(); \
     if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp); \
     tstamp = now; \
   }
-  constexpr bool poly_wait = true;
 
   { // one work item per workgroup (see the note above about a persistent loop)
     const int w = blockIdx.x;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
 #pragma unroll
           for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
           flush();
-          {
+          if (!(a.dbg & 1024)) {
             const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
             const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
 #pragma unroll
@@ -326,7 +325,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
 #pragma unroll
           for (int u = 0; u < MAXCS; ++u) {
             if (cs0 + u < cs1) {
-              if (cs0 + u + 1 < cs1) fill((u & 1) ? x0 : x1, cs0 + u + 1);
+              if (cs0 + u + 1 < cs1 && !(a.dbg & 512)) fill((u & 1) ? x0 : x1, cs0 + u + 1);
               column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
             }
           }
@@ -339,6 +338,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
       };
       // round A: periods whose windows end inside the samples written above
       if (run && !(a.dbg & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
+      RSMP_STAMP(6)
       __syncthreads();
       // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
       {
@@ -435,34 +435,54 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
 }
 
 // Outputs whose window straddles the boundary between block B-1 and block B (or precedes block 0):
-// window samples come from the seam ring.  One workgroup = one boundary x 8 channels, 32 lanes per channel.
+// window samples come from the seam ring.  One workgroup = one boundary x 8 channels, 32 lanes per channel;
+// the 2*(n-1) samples around the boundary are staged in LDS first so that the tap loop has no dependent
+// global loads (the coefficient rows are independent loads, issued 8 taps ahead).
 __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
 {
+  __shared__ double win[8][64];
   const long long B = a.d.B0 + blockIdx.x;
-  const int c = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (c >= a.d.C) return;
+  const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const int c = blockIdx.y * 8 + grp;
   const int nm1 = a.n - 1, pl = a.polyL, step = a.step;
+  const int slots = a.seam_mask + 1;
+  if (c < a.d.C) {
+    const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
+    const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
+    if (l32 < nm1) {
+      win[grp][l32] = B == 0 ? 0.0 : tail[l32];
+      win[grp][nm1 + l32] = head[l32];
+    }
+  }
+  __syncthreads();
+  if (c >= a.d.C) return;
   const long long b = a.b_offset + B * a.d.V; // first stage-1 index of block B
   const long long num0 = (b - nm1) * pl - a.at0, num1 = b * pl - a.at0;
   const long long i0 = num0 <= 0 ? 0 : (num0 + step - 1) / step;
   const long long i1 = num1 <= 0 ? 0 : (num1 + step - 1) / step;
-  const int slots = a.seam_mask + 1;
-  const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
-  const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
   const ChanRef dst = chan_ref(out, c);
-  for (long long i = i0 + (threadIdx.x & 31); i < i1; i += 32) {
+  for (long long i = i0 + l32; i < i1; i += 32) {
     const long long ai = a.at0 + i * step, q = ai / pl;
     const int ph = (int)(ai - q * pl);
     const double *__restrict__ cf = a.tab + (long long)ph * a.n;
-    const int w0 = (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= w0 < n-1
+    const double *x = win[grp] + (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= . < n-1
     double sum = 0.0;
-    for (int j = 0; j < a.n; ++j) {
-      const int w = w0 + j;
-      const double x = w < nm1 ? (B == 0 ? 0.0 : tail[w]) : head[w - nm1];
-      sum = fma(cf[j], x, sum);
-    }
+#pragma unroll 8
+    for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
     fifo_put(dst, a.out_offset2 + i, sum);
   }
+}
+
+__global__ __launch_bounds__(256) void fused_prep_kernel(FusedPrepArgs p, FusedBlock *out)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < p.nblocks) out[k] = fused_block_info(p, k);
+}
+
+hipError_t launch_fused_prep(const FusedPrepArgs &p, FusedBlock *out, hipStream_t st)
+{
+  hipLaunchKernelGGL(fused_prep_kernel, dim3((p.nblocks + 255) / 256), dim3(256), 0, st, p, out);
+  return hipGetLastError();
 }
 
 template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>

@@ -59,7 +59,34 @@ struct FusedBlock {
   int K;          // periods touched by [i_lo, i_lo + cnt)
   int KA;         // matrix-pipe variant: periods [0, KA) are computed from the first LDS image, the rest from the second
 };
-constexpr int kFusedMaxBlocks = 64;
+// Closed forms of a block's bookkeeping; evaluated by fused_prep_kernel on the device (one thread per block of the
+// launch) and by the engine for its consistency checks.
+struct FusedPrepArgs {
+  long long b_offset, B0, at0; // as in FusedArgs / DftArgs
+  int V, polyL, step, n, nblocks;
+  int two_round, KS, qb_max;   // matrix-pipe variant: split of the periods over its two LDS images
+};
+__host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, int k)
+{
+  const long long b0 = p.b_offset + (p.B0 + k) * (long long)p.V;
+  const long long nlo = b0 * p.polyL - p.at0, nhi = (b0 + p.V - p.n + 1) * p.polyL - p.at0;
+  const long long ilo = nlo <= 0 ? 0 : (nlo + p.step - 1) / p.step, ihi = nhi <= 0 ? 0 : (nhi + p.step - 1) / p.step;
+  FusedBlock fb;
+  fb.i_lo = ilo;
+  fb.cnt = ihi > ilo ? int(ihi - ilo) : 0;
+  const long long kk_lo = ilo / p.polyL;
+  fb.irel_lo = int(ilo - kk_lo * p.polyL);
+  fb.base_li = int(kk_lo * p.step - b0);
+  fb.K = fb.cnt > 0 ? int((ihi - 1) / p.polyL - kk_lo) + 1 : 0;
+  fb.KA = fb.K;
+  if (p.two_round && p.V > 12 * 256) { // periods whose (padded) windows end inside the first LDS image (kSA = 12)
+    const int a_hi = 12 * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
+    const int ka = num < 0 ? 0 : num / p.step + 1;
+    fb.KA = ka < fb.K ? ka : fb.K;
+  }
+  return fb;
+}
+constexpr int kFusedMaxBlocks = 1024; // capacity of the per-stage block table in HBM
 
 // dft -> vpoly0 fused launch (fused.hip)
 struct FusedArgs {
@@ -80,7 +107,7 @@ struct FusedArgs {
   int NGRP, KS;          // 16-residue groups, k-steps (4 taps each) of a 4-residue block's common window
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
   unsigned long long *stamps; // RSMP_STAMPS: per-phase cycle sums [8] (null in production)
-  FusedBlock blk[kFusedMaxBlocks];
+  const FusedBlock *blk; // [nblocks] in HBM, written by fused_prep_kernel ahead of the launch
 };
 
 struct PolyArgs {
@@ -113,6 +140,7 @@ hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const 
 hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
 bool fused_mfma_supported(int log2n, int log2p, int ksteps);
+hipError_t launch_fused_prep(const FusedPrepArgs &p, FusedBlock *out, hipStream_t st);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
 hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
