@@ -28,7 +28,7 @@ IN_RATE, OUT_RATE, NCH = 44100, 96000, 2
 BYTES_PER_UNIT = 4.0 * (1.0 + OUT_RATE / IN_RATE)  # 12.707 B per input channel-sample
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per fused_kernel launch from the PMC passes (profiles/r01_traffic.md); None until measured
-TRAFFIC_BYTES_PER_LAUNCH = 645.3e6  # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, mean per launch
+TRAFFIC_BYTES_PER_LAUNCH = 3276.0e6  # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, one launch = one 481 689-frame push of 256 streams
 
 
 def cpu_baseline(seconds_single=4.0, seconds_multi=8.0):
@@ -182,7 +182,7 @@ def main():
                        "out_frames_per_stream": out_frames},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                         "kernel": "rsmp::fused_kernel<12,11,2,25> (dft L2 N4096 -> vpoly0 160/147 -> float32)",
+                         "kernel": "rsmp::fused_kernel<12,11,2,7,true> (dft L2 N4096 -> vpoly0 160/147 on v_mfma_f64_4x4x4 -> float32)",
                          "launches_per_step": prof["hot_launches"] / args.steps,
                          "avg_launch_ms": round(prof["hot_ms"] / max(1, prof["hot_launches"]), 5),
                          "algorithmic_bytes_per_launch": round(units_per_step_rank * BYTES_PER_UNIT * args.steps
