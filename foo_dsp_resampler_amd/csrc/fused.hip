@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
@@ -136,21 +137,45 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
 #pragma unroll
       for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
       double2 *l2 = reinterpret_cast<double2 *>(lds);
-      if (fwd_active) {
+      if constexpr (LOG2N - LOG2P == 1) {
+        // Z[tid + s*T] = Zp[(tid + s*T) mod P] = Zp[tid + (s & 7) * T]: a forward thread (tid < TF) already
+        // holds those in its even slots; its odd slots are what thread tid + TF needs
+        if (fwd_active) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
+          for (int u = 0; u < 8; ++u) l2[tid + u * TF] = make_double2(v[2 * u + 1].x, v[2 * u + 1].y);
+        }
+        __syncthreads();
+        c64 z[8];
+        if (fwd_active) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) z[u] = v[2 * u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double2 q = l2[tid - TF + u * TF];
+            z[u] = {q.x, q.y};
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = cmul(z[s & 7], c64{g[s].x, g[s].y});
+        __syncthreads();
+      } else {
+        if (fwd_active) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) l2[tid + s * TF] = make_double2(v[s].x, v[s].y);
+        }
+        __syncthreads();
+        // Z[tid + s*T] = Zp[(tid + s*T) mod P]: only 16/L distinct entries per thread, each used L times
+        constexpr int ND = 16 >> (LOG2N - LOG2P);
+#pragma unroll
+        for (int s = 0; s < ND; ++s) {
+          const double2 z = l2[tid + s * T];
+#pragma unroll
+          for (int rep = 0; rep < 16 / ND; ++rep)
+            v[s + rep * ND] = cmul(c64{z.x, z.y}, c64{g[s + rep * ND].x, g[s + rep * ND].y});
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      // Z[tid + s*T] = Zp[(tid + s*T) mod P]: only 16/L distinct entries per thread, each used L times
-      constexpr int ND = 16 >> (LOG2N - LOG2P);
-#pragma unroll
-      for (int s = 0; s < ND; ++s) {
-        const double2 z = l2[tid + s * T];
-#pragma unroll
-        for (int rep = 0; rep < 16 / ND; ++rep)
-          v[s + rep * ND] = cmul(c64{z.x, z.y}, c64{g[s + rep * ND].x, g[s + rep * ND].y});
-      }
-      __syncthreads();
     } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -243,117 +268,135 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
           ofast = ofast && (reinterpret_cast<unsigned long long>(obase) & 7) == 0;
         }
       }
-      const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+      // The whole two-round sequence is instantiated twice and chosen by one uniform branch: FAST writes
+      // float2 frames at obase + 32-bit offsets and keeps none of the generic fifo addressing state alive
+      // (that state is what used to spill scalar registers inside the loop).
+      auto both_rounds = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca); // dead code when FAST
+        char *const obytes = reinterpret_cast<char *>(obase);
+        const int frame_bytes = ofs * 4;
 
-      // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
-      double cn_[SPAN];
-      {
-        const double *cp = a.cfm + (size_t)(wave >> 1) * SPAN * 64 + lane;
+        // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
+        double cn_[SPAN];
+        {
+          const double *cp = a.cfm + (size_t)(wave >> 1) * SPAN * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
-      }
-      // Outputs of an item are stored at the start of the NEXT item, after that item's wait for its A tile:
-      // on gfx950 loads and stores share one in-order counter (vmcnt), so a store issued just before the
-      // wait would put a full store round trip into it.
-      constexpr int MAXCS = 4; // column steps per item (host: at most 32 periods per block)
-      double pA[MAXCS], pB[MAXCS];
-      int pend_n = 0, pend_g = 0, pend_cs0 = 0, pend_kb = 0, pend_ke = 0;
-      auto flush = [&]() {
+          for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
+        }
+        // Outputs of an item are stored at the start of the NEXT item, after that item's wait for its A tile:
+        // on gfx950 loads and stores share one in-order counter (vmcnt), so a store issued just before the
+        // wait would put a full store round trip into it.
+        constexpr int MAXCS = 4; // column steps per item (host: at most 32 periods per block)
+        double pA[MAXCS], pB[MAXCS];
+        int pend_n = 0;       // column steps waiting to be stored
+        int pend_ib = 0;      // this lane's output index (relative to period kk_lo) in the first of them
+        int pend_hi = 0;      // exclusive bound of that index: min(irel_hi, ke * pl); -1 when the lane's residue >= pl
+        int pend_allv = 0;    // bit u: every lane's output of step u is inside the block's range (uniform)
+        auto flush = [&]() {
 #pragma unroll
-        for (int u = 0; u < MAXCS; ++u) {
-          if (u < pend_n) {
-            const int kr = pend_kb + 4 * (pend_cs0 + u) + jq;
-            const int rD = 16 * pend_g + 4 * bq + hi;
-            const int ib = kr * pl + rD;
-            if (kr < pend_ke && rD < pl && ib >= fb.irel_lo && ib < irel_hi) {
-              const int orel = ib - fb.irel_lo;
-              if (ofast) {
-                *reinterpret_cast<float2 *>(obase + (long long)orel * ofs) = make_float2((float)pA[u], (float)pB[u]);
-              } else {
-                const long long oabs = a.out_offset2 + fb.i_lo + orel;
-                fifo_put(oa, oabs, pA[u]);
-                if (hasb) fifo_put(ob, oabs, pB[u]);
+          for (int u = 0; u < MAXCS; ++u) {
+            if (u < pend_n) {
+              const int ib = pend_ib + u * 4 * pl;
+              if (((pend_allv >> u) & 1) || (ib >= fb.irel_lo && ib < pend_hi)) {
+                const int orel = ib - fb.irel_lo;
+                if (FAST) {
+                  *reinterpret_cast<float2 *>(obytes + orel * frame_bytes) = make_float2((float)pA[u], (float)pB[u]);
+                } else {
+                  const long long oabs = a.out_offset2 + fb.i_lo + orel;
+                  fifo_put(oa, oabs, pA[u]);
+                  if (hasb) fifo_put(ob, oabs, pB[u]);
+                }
               }
             }
           }
-        }
-        pend_n = 0;
-      };
-      // periods [kb, ke) of the block from the LDS image `xs` (indexed by sample number); li_lo/li_hi clamp
-      // the window start of outputs that are not stored anyway (block edges) into the image
-      auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
-        const int ncs = (ke - kb + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
-        for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
-          const int g = it >> 1, second = (it + (it >> 2)) & 1; // halves alternate so the waves stay balanced
-          int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
-          // column steps whose 64 outputs all lie outside [irel_lo, irel_hi) (block edges) are skipped
-          while (cs0 < cs1 && (kb + 4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
-          while (cs1 > cs0 && (kb + 4 * (cs1 - 1)) * pl + 16 * g >= irel_hi) --cs1;
-          double ca_[SPAN];
+          pend_n = 0;
+        };
+        // periods [kb, ke) of the block from the LDS image `xs` (indexed by sample number); li_lo/li_hi clamp
+        // the window start of outputs that are not stored anyway (block edges) into the image
+        auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
+          const int ncs = (ke - kb + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
+          for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
+            const int g = it >> 1, second = (it + (it >> 2)) & 1; // halves alternate so the waves stay balanced
+            int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
+            // column steps whose 64 outputs all lie outside [irel_lo, irel_hi) (block edges) are skipped
+            while (cs0 < cs1 && (kb + 4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
+            while (cs1 > cs0 && (kb + 4 * (cs1 - 1)) * pl + 16 * g >= irel_hi) --cs1;
+            double ca_[SPAN];
 #pragma unroll
-          for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
-          flush();
-          if (!(a.dbg & 1024)) {
-            const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
-            const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
+            for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
+            flush();
+            if (!(a.dbg & 1024)) {
+              const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
+              const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
-          }
-          int rb = 16 * g + 4 * bq;
-          if (rb >= pl) rb = 0; // idle block: all-zero coefficients, any in-range window will do
-          const int qb = (at0 + rb * step) / pl + fb.base_li + hi;
-          // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
-          // step's reads are issued before this step's MFMA chains so their latency hides behind them, into
-          // the other of two register images (no copies)
-          double2 x0[SPAN], x1[SPAN];
-          auto fill = [&](double2 (&x)[SPAN], int cs) {
-            const int li = max(li_lo, min(li_hi, qb + min(kb + 4 * cs + jq, ke - 1) * step));
-            const double2 *xp = xs + li;
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) x[s] = xp[4 * s];
-          };
-          auto column_step = [&](const double2 (&x)[SPAN], double &accA, double &accB) {
-            accA = 0.0;
-            accB = 0.0;
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) {
-              accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].x, accA, 0, 0, 0);
-              accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].y, accB, 0, 0, 0);
+              for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
             }
-          };
-          if (cs0 < cs1) fill(x0, cs0);
+            int rb = 16 * g + 4 * bq;
+            if (rb >= pl) rb = 0; // idle block: all-zero coefficients, any in-range window will do
+            const int qb = (at0 + rb * step) / pl + fb.base_li + hi;
+            // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
+            // step's reads are issued before this step's MFMA chains so their latency hides behind them, into
+            // the other of two register images (no copies)
+            double2 x0[SPAN], x1[SPAN];
+            auto fill = [&](double2 (&x)[SPAN], int cs) {
+              const int li = max(li_lo, min(li_hi, qb + min(kb + 4 * cs + jq, ke - 1) * step));
+              const double2 *xp = xs + li;
 #pragma unroll
-          for (int u = 0; u < MAXCS; ++u) {
-            if (cs0 + u < cs1) {
-              if (cs0 + u + 1 < cs1 && !(a.dbg & 512)) fill((u & 1) ? x0 : x1, cs0 + u + 1);
-              column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
+              for (int s = 0; s < SPAN; ++s) x[s] = xp[4 * s];
+            };
+            auto column_step = [&](const double2 (&x)[SPAN], double &accA, double &accB) {
+              accA = 0.0;
+              accB = 0.0;
+#pragma unroll
+              for (int s = 0; s < SPAN; ++s) {
+                accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].x, accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].y, accB, 0, 0, 0);
+              }
+            };
+            if (cs0 < cs1) fill(x0, cs0);
+#pragma unroll
+            for (int u = 0; u < MAXCS; ++u) {
+              if (cs0 + u < cs1) {
+                if (cs0 + u + 1 < cs1 && !(a.dbg & 512)) fill((u & 1) ? x0 : x1, cs0 + u + 1);
+                column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
+              }
+            }
+            // bookkeeping for the deferred stores
+            const int rD = 16 * g + 4 * bq + hi, k0 = kb + 4 * cs0;
+            pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
+            pend_ib = (k0 + jq) * pl + rD;
+            pend_hi = rD < pl ? min(irel_hi, ke * pl) : -1;
+            pend_allv = 0;
+            if (16 * g + 15 < pl) {
+#pragma unroll
+              for (int u = 0; u < MAXCS; ++u)
+                if (k0 + 4 * u + 3 < ke && (k0 + 4 * u) * pl + 16 * g >= fb.irel_lo && (k0 + 4 * u + 3) * pl + 16 * g + 15 < irel_hi)
+                  pend_allv |= 1 << u;
             }
           }
-          pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
-          pend_g = g;
-          pend_cs0 = cs0;
-          pend_kb = kb;
-          pend_ke = ke;
-        }
-      };
-      // round A: periods whose windows end inside the samples written above
-      if (run && !(a.dbg & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
-      RSMP_STAMP(6)
-      __syncthreads();
-      // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
-      {
-        double2 *l2 = reinterpret_cast<double2 *>(lds);
+        };
+        // round A: periods whose windows end inside the samples written above
+        if (run && !(a.dbg & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
+        RSMP_STAMP(6)
+        __syncthreads();
+        // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
+        {
+          double2 *l2 = reinterpret_cast<double2 *>(lds);
 #pragma unroll
-        for (int s = kSB0; s < 16; ++s) {
-          const int n = tid + s * T;
-          if (n < V) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
+          for (int s = kSB0; s < 16; ++s) {
+            const int n = tid + s * T;
+            if (n < V) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
+          }
+          if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
         }
-        if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
-      }
-      __syncthreads();
-      if (run && fb.KA < fb.K && !(a.dbg & 32))
-        poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * SPAN);
-      flush();
+        __syncthreads();
+        if (run && fb.KA < fb.K && !(a.dbg & 32))
+          poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * SPAN);
+        flush();
+      };
+      if (ofast) both_rounds(std::true_type{});
+      else both_rounds(std::false_type{});
     } else
     // ---------------------------------------------------------------- polyphase FIR from LDS (vector pipe)
     if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
