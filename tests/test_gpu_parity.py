@@ -78,6 +78,9 @@ def test_availability_matches_oracle_after_every_push(facts):
     (48000, 32000, 2, {}),          # dft L2 M3: time-domain decimation
     (44100, 176400, 2, {}),         # dft L4 only
     (11025, 44100, 5, {}),          # 5 channels
+    (44100, 96000, 1, {}),          # headline chain, mono: last pair has one channel, generic store path
+    (44100, 48000, 3, {}),          # odd channel count through the fused kernel
+    (11025, 48000, 2, {}),          # dft L2 -> vpoly0 -> dft L4: the fused kernel feeds an fp64 ring
     (44100, 48000, 2, {"quality": 1}),                      # Normal
     (44100, 96000, 2, {"bandwidth": 90.0, "allow_aliasing": 1}),
     (44100, 44100, 2, {}),          # no stages at all: pass-through
