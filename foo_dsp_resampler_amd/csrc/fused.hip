@@ -275,7 +275,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
         constexpr bool FAST = decltype(fast_tag)::value;
         const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca); // dead code when FAST
         char *const obytes = reinterpret_cast<char *>(obase);
-        const int frame_bytes = ofs * 4;
+        const int frame_bytes = ofs * 4, period4_bytes = 4 * pl * frame_bytes; // output bytes per frame / per column step
 
         // A operands are double-buffered: the next item's tile is in flight (L2 latency) while this one computes
         double cn_[SPAN];
@@ -293,6 +293,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
         int pend_ib = 0;      // this lane's output index (relative to period kk_lo) in the first of them
         int pend_hi = 0;      // exclusive bound of that index: min(irel_hi, ke * pl); -1 when the lane's residue >= pl
         int pend_allv = 0;    // bit u: every lane's output of step u is inside the block's range (uniform)
+        int pend_off = 0;     // FAST: byte offset from obase of this lane's frame in the first pending step
         auto flush = [&]() {
 #pragma unroll
           for (int u = 0; u < MAXCS; ++u) {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
               if (((pend_allv >> u) & 1) || (ib >= fb.irel_lo && ib < pend_hi)) {
                 const int orel = ib - fb.irel_lo;
                 if (FAST) {
-                  *reinterpret_cast<float2 *>(obytes + orel * frame_bytes) = make_float2((float)pA[u], (float)pB[u]);
+                  *reinterpret_cast<float2 *>(obytes + (pend_off + u * period4_bytes)) = make_float2((float)pA[u], (float)pB[u]);
                 } else {
                   const long long oabs = a.out_offset2 + fb.i_lo + orel;
                   fifo_put(oa, oabs, pA[u]);
@@ -328,19 +329,21 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
             flush();
             if (!(a.dbg & 1024)) {
               const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
-              const double *cp = a.cfm + (size_t)(nx >> 1) * SPAN * 64 + lane;
+              const double *cp = a.cfm + (nx >> 1) * (SPAN * 64);    // uniform base, lane offset added by the load
 #pragma unroll
-              for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64];
+              for (int s = 0; s < SPAN; ++s) cn_[s] = cp[s * 64 + lane];
             }
             int rb = 16 * g + 4 * bq;
             if (rb >= pl) rb = 0; // idle block: all-zero coefficients, any in-range window will do
-            const int qb = (at0 + rb * step) / pl + fb.base_li + hi;
+            // window start of this lane's block in period kb + jq; later column steps add a uniform 4 * step
+            const int qb = (at0 + rb * step) / pl + fb.base_li + hi + (kb + jq) * step;
+            const int step4 = 4 * step;
             // B operands of one column step: SPAN ds_read_b128 with immediate offsets off one address; the next
             // step's reads are issued before this step's MFMA chains so their latency hides behind them, into
             // the other of two register images (no copies)
             double2 x0[SPAN], x1[SPAN];
             auto fill = [&](double2 (&x)[SPAN], int cs) {
-              const int li = max(li_lo, min(li_hi, qb + min(kb + 4 * cs + jq, ke - 1) * step));
+              const int li = max(li_lo, min(li_hi, qb + cs * step4)); // periods past ke - 1 clamp to li_hi as well
               const double2 *xp = xs + li;
 #pragma unroll
               for (int s = 0; s < SPAN; ++s) x[s] = xp[4 * s];
@@ -366,6 +369,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(An
             const int rD = 16 * g + 4 * bq + hi, k0 = kb + 4 * cs0;
             pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
             pend_ib = (k0 + jq) * pl + rD;
+            pend_off = (pend_ib - fb.irel_lo) * frame_bytes;
             pend_hi = rD < pl ? min(irel_hi, ke * pl) : -1;
             pend_allv = 0;
             if (16 * g + 15 < pl) {
