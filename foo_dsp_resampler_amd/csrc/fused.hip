@@ -26,10 +26,10 @@
 namespace rsmp {
 
 constexpr int kPad = 32;      // LDS guard samples around each channel's block
-constexpr int kSpanMax = 32;
+constexpr int kSpanMax = 32;  // largest window length (taps + offset spread) the register tile supports
 // matrix-pipe variant (N = 4096): LDS holds the block's samples in two rounds so that three workgroups fit a CU:
 // round A = register slots [0, kSA) i.e. samples [0, 256*kSA) plus kPad more, round B = slots [kSB0, 16)
-constexpr int kSA = 12, kSB0 = 11;  // largest window length (taps + offset spread) the register tile supports
+constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 
 // SPAN = window length of a G-tile (compile time, so the whole tap loop is straight-line code and the LDS
 // reads are issued ahead of the FMAs); a.span <= SPAN, coefficients beyond a.span are zero.
@@ -43,7 +43,7 @@ constexpr int kSA = 12, kSB0 = 11;  // largest window length (taps + offset spre
 // MF variant (polyphase on the fp64 matrix pipe): see the "polyphase FIR on v_mfma_f64_4x4x4" section below;
 // SPAN then counts k-steps (4 taps each) of a 4-residue block's common window.
 template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>
-__global__ __launch_bounds__((1 << LOG2N) / 16, MF ? 3 : 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
+__global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused_kernel(AnyView in, AnyView out, FusedArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P;
   constexpr int T = N / 16, TF = P / 16;

@@ -59,6 +59,14 @@ struct FusedBlock {
   int K;          // periods touched by [i_lo, i_lo + cnt)
   int KA;         // matrix-pipe variant: periods [0, KA) are computed from the first LDS image, the rest from the second
 };
+// Matrix-pipe variant of the fused kernel (N = 4096, 256 threads): the block's samples sit in LDS in two rounds,
+// round A = register slots [0, kFusedSA) of the inverse FFT (samples [0, 256*kFusedSA) plus a 32-sample margin),
+// round B = slots [kFusedSB0, 16).  RSMP_WG4 sizes them for four workgroups per CU instead of three.
+#ifndef RSMP_WG4
+#define RSMP_WG4 0
+#endif
+constexpr int kFusedSA = RSMP_WG4 ? 9 : 12, kFusedSB0 = kFusedSA - 1, kFusedWaves = RSMP_WG4 ? 4 : 3;
+
 // Closed forms of a block's bookkeeping; evaluated by fused_prep_kernel on the device (one thread per block of the
 // launch) and by the engine for its consistency checks.
 struct FusedPrepArgs {
@@ -79,8 +87,8 @@ __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, i
   fb.base_li = int(kk_lo * p.step - b0);
   fb.K = fb.cnt > 0 ? int((ihi - 1) / p.polyL - kk_lo) + 1 : 0;
   fb.KA = fb.K;
-  if (p.two_round && p.V > 12 * 256) { // periods whose (padded) windows end inside the first LDS image (kSA = 12)
-    const int a_hi = 12 * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
+  if (p.two_round && p.V > kFusedSA * 256) { // periods whose (padded) windows end inside the first LDS image
+    const int a_hi = kFusedSA * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
     const int ka = num < 0 ? 0 : num / p.step + 1;
     fb.KA = ka < fb.K ? ka : fb.K;
   }
