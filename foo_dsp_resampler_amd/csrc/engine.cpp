@@ -708,10 +708,19 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.L = sp.L;
         a.phase_bits = sp.phase_bits;
         const double in_per_out = sp.order == 0 ? double(step) / sp.L : double(step) / 4294967296.0;
+        // LDS: window of the tile, plus (rational stages) the whole coefficient table when both fit 64 KB;
+        // the kernel's 32-bit clock needs tile * step < 2^31
+        const size_t tab_bytes = sp.order == 0 ? size_t(sp.L) * sp.n * 8 : 0;
+        const bool tab_lds = sp.order == 0 && tab_bytes <= 40 * 1024;
+        const double lds_for_window = tab_lds ? double(64 * 1024 - 16) - double(tab_bytes) : 48.0 * 1024;
         int tile = 2048;
-        while (tile > 256 && (tile * in_per_out + sp.n + 4) * 8 > 48 * 1024) tile >>= 1;
+        while (tile > 256 && ((tile * in_per_out + sp.n + 4) * 8 > lds_for_window ||
+                              (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0)))
+          tile >>= 1;
+        if (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0) return kInternal;
         a.tile = tile;
-        a.win = int(tile * in_per_out) + sp.n + 4;
+        a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
+        a.tab_lds = tab_lds;
         const int pi = prof_begin(false);
         HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                             src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,

@@ -191,32 +191,52 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_kernel(AnyView 
   const long long q1 = ORDER == 0 ? A1 / a.L : (A1 >> 32);
   const int wlen = (int)(q1 - q0) + a.n;
   for (int i = tid; i < wlen; i += 256) win[i] = fifo_get(src, a.rd + q0 + i);
+  // rational stage: the whole coefficient table rides in LDS behind the window when it fits (a.tab_lds)
+  const double *__restrict__ tab = a.tab;
+  if (ORDER == 0 && a.tab_lds) {
+    double *t = win + a.win;
+    for (int i = tid; i < a.L * a.n; i += 256) t[i] = a.tab[i];
+    tab = t;
+  }
   __syncthreads();
 
-  for (int u = tid; u < cnt; u += 256) {
-    const long long A = a.at + (i0 + u) * a.step;
-    double sum = 0.0;
-    if (ORDER == 0) {
-      const long long q = A / a.L;
-      const int ph = (int)(A - q * a.L);
-      const double *__restrict__ cf = a.tab + (long long)ph * a.n;
-      const double *x = win + (q - q0);
+  if (ORDER == 0) {
+    // clock of output i0 + u relative to the tile's first window: t = t0 + u * step, all in 32 bits; a thread
+    // walks u = tid, tid + 256, ... with an incremental (q, phase) update, one division per thread
+    const unsigned L = (unsigned)a.L, step = (unsigned)a.step;
+    const unsigned t0 = (unsigned)(A0 - q0 * a.L) + (unsigned)tid * step;
+    unsigned q = t0 / L, ph = t0 - q * L;
+    const unsigned dq = (256u * step) / L, dph = 256u * step - dq * L;
+    for (int u = tid; u < cnt; u += 256) {
+      const double *cf = tab + ph * a.n;
+      const double *x = win + q;
+      double sum = 0.0;
+#pragma unroll 4
       for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
-    } else {
+      fifo_put(dst, a.out_abs + i0 + u, sum);
+      q += dq;
+      ph += dph;
+      if (ph >= L) { ph -= L; ++q; }
+    }
+  } else {
+    for (int u = tid; u < cnt; u += 256) {
+      const long long A = a.at + (i0 + u) * a.step;
       const long long q = A >> 32;
       const unsigned frac = (unsigned)A;
       const int ph = (int)(frac >> (32 - a.phase_bits));
       const double t = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
       const double *__restrict__ cf = a.tab + (long long)ph * a.n * (ORDER + 1);
       const double *x = win + (q - q0);
-      for (int j = 0; j < a.n; ++j, cf += ORDER + 1) {
-        double w = cf[0];
+      double sum = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < a.n; ++j) { // coefficient loads of four taps in flight
+        double w = cf[j * (ORDER + 1)];
 #pragma unroll
-        for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[o]);
+        for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[j * (ORDER + 1) + o]);
         sum = fma(w, x[j], sum);
       }
+      fifo_put(dst, a.out_abs + i0 + u, sum);
     }
-    fifo_put(dst, a.out_abs + i0 + u, sum);
   }
 }
 
@@ -300,7 +320,7 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const long long tiles = (a.count + a.tile - 1) / a.tile;
   dim3 grid((unsigned)tiles, a.C), block(256);
-  const size_t lds_bytes = sizeof(double) * size_t(a.win);
+  const size_t lds_bytes = sizeof(double) * (size_t(a.win) + (order == 0 && a.tab_lds ? size_t(a.L) * a.n : 0));
   switch (order) {
     case 0: hipLaunchKernelGGL(poly_kernel<0>, grid, block, lds_bytes, st, in, out, a); break;
     case 1: hipLaunchKernelGGL(poly_kernel<1>, grid, block, lds_bytes, st, in, out, a); break;

@@ -126,6 +126,7 @@ struct PolyArgs {
   long long out_abs;     // absolute index (in the destination fifo) of output 0 of this launch
   long long count;       // outputs to produce
   int C, n, L, phase_bits, tile, win;
+  int tab_lds;           // order 0: copy the [L][n] table into LDS behind the window (it fits)
 };
 
 struct HalfArgs {
