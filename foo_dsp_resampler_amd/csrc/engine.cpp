@@ -192,55 +192,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     // periods a block can touch: ceil(outputs per block / L) + 1; chunk length fixed from it
     const int Kmax = int(((long long)V * p.L / pstep + p.L - 1) / p.L) + 2;
     fu.kper = (Kmax + fu.KC - 1) / fu.KC;
-    // Lane -> item map.  In the tap loop every lane reads 16-byte LDS elements li + mm with
-    // li = qr0(m) + (kc*kper + k)*step + block shift; ds_read_b128 serves 16 lanes per cycle in the fixed
-    // groups below, conflict-free iff their li are distinct mod 16.  Items stay in their natural wave (so a
-    // wave's stores still cover one contiguous range); inside a wave they are dealt to the four hardware
-    // groups so that equal residues land in different groups.
-    std::vector<int> perm(threads);
-    {
-      static const int hw_group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                          {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
-                                          {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
-                                          {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-      for (int w0 = 0; w0 < threads; w0 += 64) {
-        std::vector<int> byres[16], idle;
-        for (int it = w0; it < w0 + 64; ++it) {
-          const int m = it % NG, kc = it / NG;
-          if (kc >= fu.KC) { idle.push_back(it); continue; }
-          const long long li = (at0 + (long long)(G * m) * pstep) / p.L + (long long)kc * fu.kper * pstep;
-          byres[li & 15].push_back(it);
-        }
-        std::vector<int> grp[4];
-        int next = 0;
-        for (int pass = 0; pass < 64; ++pass) // deal residue classes round-robin, fullest groups skipped
-          for (int r = 0; r < 16; ++r)
-            if (pass < int(byres[r].size())) {
-              int g = -1;
-              for (int t = 0; t < 4; ++t) {
-                const int c = (next + t) & 3;
-                if (grp[c].size() < 16) { g = c; break; }
-              }
-              grp[g].push_back(byres[r][pass]);
-              next = (g + 1) & 3;
-            }
-        for (int it : idle)
-          for (int c = 0; c < 4; ++c)
-            if (grp[c].size() < 16) { grp[c].push_back(it); break; }
-        for (int c = 0; c < 4; ++c)
-          for (int k = 0; k < 16; ++k) perm[w0 + hw_group[c][k]] = grp[c][k];
-      }
-      // measured on MI355X: the dealt map is 7 % SLOWER than the identity (stores lose their lane order), so the
-      // identity is the default; RSMP_PERM=1 enables the experiment
-      if (!getenv("RSMP_PERM")) for (int t = 0; t < threads; ++t) perm[t] = t;
-      void *d = nullptr;
-      if ((rc = upload(perm.data(), perm.size() * sizeof(int), &d)) != kOk) return rc;
-      fu.perm = static_cast<int *>(d);
-    }
     { // coefficient tiles, one per thread of the fused kernel: tile[mm][g] = row(phase of residue G*m+g)[mm - d_g]
       std::vector<double> tiles(size_t(32) * G * threads, 0.0);
       for (int t = 0; t < threads; ++t) {
-        const int m = perm[t] % NG, kc = perm[t] / NG;
+        const int m = t % NG, kc = t / NG;
         if (kc >= fu.KC) continue;
         const int q0 = (at0 + G * m * pstep) / p.L;
         for (int g = 0; g < G; ++g) {
@@ -405,7 +360,6 @@ Engine::~Engine()
   for (Fuse &f : fuse_) {
     if (f.seam) (void)hipFree(f.seam);
     if (f.cft) (void)hipFree(f.cft);
-    if (f.perm) (void)hipFree(f.perm);
     if (f.cfm) (void)hipFree(f.cfm);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
@@ -645,7 +599,6 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.NG = fu.NG;
           fa.KC = fu.KC;
           fa.kper = fu.kper;
-          fa.perm = fu.perm;
           fa.cfm = fu.cfm;
           fa.NGRP = fu.NGRP;
           fa.KS = fu.KS;

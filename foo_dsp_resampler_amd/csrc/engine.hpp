@@ -109,7 +109,7 @@ private:
   std::vector<DftGpu> dftg_;        // indexed by stage
   std::vector<long long> hist_;     // per fifo: items below rd that must stay readable
   // fused dft->vpoly0 path
-  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int *perm = nullptr; int slots = 0;
+  struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0;
                 double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0;
                 FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage

@@ -61,8 +61,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   // ------------------------------------------------------------------ per-thread polyphase constants
   // thread -> (residue group m, period chunk kc); residues r0..r0+G-1 (mod polyL)
   const int pl = a.polyL, step = a.step, at0 = (int)a.at0;
-  const int item = MF ? 0 : a.perm[tid]; // host-chosen lane -> (residue group, period chunk) map, see engine.cpp
-  const int m = item % a.NG, kc = item / a.NG;
+  const int m = MF ? 0 : tid % a.NG, kc = MF ? 0 : tid / a.NG;
   const bool poly_thread = kc < a.KC;
   const int r0 = G * m;
   const int qr0 = (at0 + r0 * step) / pl;

@@ -110,7 +110,6 @@ struct FusedArgs {
   int span;              // n + largest window offset inside a G-tile
   int NG, KC;            // residue groups, period chunks (NG * KC <= threads)
   int kper;              // periods per chunk
-  const int *perm;       // [threads] lane -> item (kc * NG + m), chosen so LDS window reads avoid bank conflicts
   const double *cfm;     // matrix-pipe variant: A operands [16-residue group][k-step][lane]; null = vector variant
   int NGRP, KS;          // 16-residue groups, k-steps (4 taps each) of a 4-residue block's common window
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
