@@ -4,6 +4,7 @@
 
 #include "engine.hpp"
 #include "plugin_host.hpp"
+#include "lpc.hpp"
 
 #include <cstring>
 #include <new>
@@ -334,6 +335,12 @@ int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames)
   std::memcpy(dst, c.data.data(), c.frames * c.channels * sizeof(float));
   h->out.pop_front();
   return RR_OK;
+}
+
+void DSPR_lpc_extrapolate(fb_sample_t *data, size_t data_len, int nch, int lpc_order, size_t extra_bkwd, size_t extra_fwd)
+{
+  if (!data || nch <= 0 || lpc_order <= 0) return;
+  guarded([&] { rsmp::lpc_extrapolate(data, data_len, nch, lpc_order, extra_bkwd, extra_fwd); return 0; });
 }
 
 } // extern "C"

@@ -16,7 +16,7 @@ EXPECTED_SYMBOLS = [
     "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
     "RRX_describe_plan", "RRX_plan_table",
     "DSPR_create", "DSPR_destroy", "DSPR_on_chunk", "DSPR_end_of_track", "DSPR_flush", "DSPR_get_latency",
-    "DSPR_peek_output", "DSPR_pop_output",
+    "DSPR_peek_output", "DSPR_pop_output", "DSPR_lpc_extrapolate",
 ]
 
 

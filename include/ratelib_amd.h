@@ -81,6 +81,9 @@ double DSPR_get_latency(const DSPR_handle *h); /* foo_dsp_rate.cpp:315-322 */
  * it into `dst` (frames * channels floats). */
 int DSPR_peek_output(const DSPR_handle *h, size_t *frames, unsigned *channels, unsigned *sample_rate);
 int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames);
+/* The host-side LPC edge extrapolator the plugin layer uses, with the signature of lpc_extrapolate2
+ * (lpc/lpc.h:25): writes extra_bkwd frames before data[0] and extra_fwd frames after data[data_len*nch). */
+void DSPR_lpc_extrapolate(fb_sample_t *data, size_t data_len, int nch, int lpc_order, size_t extra_bkwd, size_t extra_fwd);
 
 #ifdef __cplusplus
 }

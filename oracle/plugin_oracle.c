@@ -101,6 +101,12 @@ static void lpc_extrapolate(float *data, size_t data_len, int nch, int order, si
   free(a); free(r); free(line);
 }
 
+/* exported for tests: same signature as lpc_extrapolate2 of lpc/lpc.h:25 */
+void orc_lpc_extrapolate(float *data, size_t data_len, int nch, int order, size_t extra_bkwd, size_t extra_fwd)
+{
+  lpc_extrapolate(data, data_len, nch, order, extra_bkwd, extra_fwd);
+}
+
 /* ------------------------------------------------------------------ util.h:24-55 */
 static unsigned gcd_u(unsigned a, unsigned b)
 {
