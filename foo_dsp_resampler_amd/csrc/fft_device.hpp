@@ -214,8 +214,12 @@ __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16],
   }
 }
 
-template <int LOG2M, int R, int NS, int DIR, int MODE, bool LAST>
-__device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
+// One pass.  PF > 0 (twiddle prefetch): this pass's twiddles were loaded into `wcur` ahead of the previous
+// exchange, and the first PF twiddles of the NEXT pass (table `twn`, butterfly stride NSN) are loaded into `wnext`
+// before this pass's exchange, so their L2 round trip runs behind the LDS round trip instead of after it.
+template <int LOG2M, int R, int NS, int DIR, int MODE, bool LAST, int PF = 0, int NSN = 1>
+__device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds,
+                                         const double2 (&wcur)[15], double2 (&wnext)[15], const double2 *__restrict__ twn)
 {
   constexpr int T = (1 << LOG2M) / 16, NB = 16 / R;
   if (active) {
@@ -228,7 +232,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
         const int k = (tid + t * T) & (NS - 1);
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-          const double2 w = tw[(r - 1) * NS + k];
+          const double2 w = (PF > 0 && r - 1 < PF && NB == 1) ? wcur[r - 1] : tw[(r - 1) * NS + k];
           b[r] = DIR > 0 ? cmul(b[r], c64{w.x, w.y}) : cmulc(b[r], c64{w.x, w.y});
         }
       }
@@ -238,6 +242,11 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
     }
   }
   if (!LAST) {
+    if (PF > 0 && active) {
+      const int kn = tid & (NSN - 1);
+#pragma unroll
+      for (int r = 1; r <= PF; ++r) wnext[r - 1] = twn[(r - 1) * NSN + kn];
+    }
     int pos[16];
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
@@ -250,14 +259,19 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 }
 
 // Full transform.  `tw` points at this size's table (fft_twiddle_count(LOG2M) entries).
-template <int LOG2M, int DIR, int MODE>
+// PF = number of twiddles (of 15) per pass that are prefetched ahead of the preceding exchange (registers: 4 each).
+template <int LOG2M, int DIR, int MODE, int PF = 0>
 __device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int R0 = fft_first_radix(LOG2M), NP = fft_num_passes(LOG2M);
-  fft_pass<LOG2M, R0, 1, DIR, MODE, NP == 1>(v, tid, active, tw, lds);
-  if constexpr (NP >= 2) fft_pass<LOG2M, 16, R0, DIR, MODE, NP == 2>(v, tid, active, tw, lds);
-  if constexpr (NP >= 3) fft_pass<LOG2M, 16, R0 * 16, DIR, MODE, NP == 3>(v, tid, active, tw + 15 * R0, lds);
-  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4>(v, tid, active, tw + 15 * R0 * 17, lds);
+  double2 wa[15], wb[15];
+  fft_pass<LOG2M, R0, 1, DIR, MODE, NP == 1, NP >= 2 ? PF : 0, R0>(v, tid, active, tw, lds, wa, wa, tw);
+  if constexpr (NP >= 2)
+    fft_pass<LOG2M, 16, R0, DIR, MODE, NP == 2, NP >= 3 ? PF : 0, R0 * 16>(v, tid, active, tw, lds, wa, wb, tw + 15 * R0);
+  if constexpr (NP >= 3)
+    fft_pass<LOG2M, 16, R0 * 16, DIR, MODE, NP == 3, NP >= 4 ? PF : 0, R0 * 256>(v, tid, active, tw + 15 * R0, lds, wb, wa,
+                                                                                  tw + 15 * R0 * 17);
+  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4, 0, 1>(v, tid, active, tw + 15 * R0 * 17, lds, wa, wb, tw);
 }
 
 } // namespace rsmp

@@ -23,6 +23,14 @@
 #include <cstdlib>
 #include <cstdio>
 
+// twiddles per pass prefetched ahead of the preceding LDS exchange (forward / inverse transform of the MF variant)
+#ifndef RSMP_PFW
+#define RSMP_PFW 15
+#endif
+#ifndef RSMP_PFI
+#define RSMP_PFI 8
+#endif
+
 namespace rsmp {
 
 constexpr int kPad = 32;      // LDS guard samples around each channel's block
@@ -129,7 +137,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
 
     RSMP_STAMP(0)
     // ---------------------------------------------------------------- FFT-FIR (as dft_kernel)
-    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
+    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0, MF ? RSMP_PFW : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
     RSMP_STAMP(1)
     if constexpr (LOG2P < LOG2N) {
       double2 g[16]; // issued before the exchange so the L2 latency overlaps it
@@ -183,7 +191,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       }
     }
     RSMP_STAMP(2)
-    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, MF ? 2 : 0>(v, tid, true, a.d.tw_inv, lds);
+    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, MF ? 2 : 0, MF ? RSMP_PFI : 0>(v, tid, true, a.d.tw_inv, lds);
     RSMP_STAMP(3)
 
     // coefficient tile of this thread: rows of its G phases shifted to a common window start and zero
