@@ -252,6 +252,47 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     const size_t cap = size_t(double(per_launch) / std::max(ahead, 1e-9));
     fused_slab_cap = fused_slab_cap ? std::min(fused_slab_cap, cap) : cap;
   }
+  // rational polyphase stages that are not fused run as a matrix-pipe stage of their own (polymf.hip) when
+  // they have enough phases to fill 16-row tiles
+  polymf_.assign(ns, PolyMf());
+  for (int i = 0; i < ns; ++i) {
+    const StageSpec &p = plan_.stages[i];
+    if (p.kind != StageKind::Poly || p.order != 0 || (i > 0 && fuse_[i - 1].on) || p.L < 64) continue;
+    if (getenv("RSMP_NO_MFMA") || getenv("RSMP_NO_POLYMF")) continue;
+    const int pstep = int(p.step64 >> 32), at0 = int(p.at0 >> 32);
+    int d4 = 0;
+    for (int rb = 0; rb < p.L; rb += 4) {
+      const long long a0 = at0 + (long long)rb * pstep, a1 = at0 + (long long)std::min(rb + 3, p.L - 1) * pstep;
+      d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
+    }
+    const int KS = std::max(7, (p.n + d4 + 3) / 4), NGRP = (p.L + 15) / 16;
+    if (!polymf_supported(KS)) continue;
+    // tile length: at most 2048 stage-input samples and at most 30 output periods per tile
+    int Vt = 2048;
+    while (Vt > 256 && ((long long)Vt * p.L / pstep + p.L - 1) / p.L + 2 > 30) Vt -= 256;
+    if (((long long)Vt * p.L / pstep + p.L - 1) / p.L + 2 > 30) continue;
+    std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
+    for (int g = 0; g < NGRP; ++g)
+      for (int s = 0; s < KS; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int k = lane >> 4, bq = (lane >> 2) & 3, ii = lane & 3;
+          const int rb = 16 * g + 4 * bq, r = rb + ii;
+          if (r >= p.L) continue;
+          const int qb = (at0 + rb * pstep) / p.L;
+          const int ar = at0 + r * pstep, q = ar / p.L, ph = ar - q * p.L;
+          const int j = 4 * s + k - (q - qb);
+          if (j >= 0 && j < p.n) am[(size_t(g) * KS + s) * 64 + lane] = plan_.poly_table[size_t(ph) * p.n + j];
+        }
+    PolyMf &pm = polymf_[i];
+    void *dm = nullptr;
+    if ((rc = upload(am.data(), am.size() * sizeof(double), &dm)) != kOk) return rc;
+    pm.cfm = static_cast<double *>(dm);
+    pm.KS = KS;
+    pm.NGRP = NGRP;
+    pm.Vt = Vt;
+    pm.blk_cap = 4096;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pm.blk), size_t(pm.blk_cap) * sizeof(FusedBlock)));
+  }
   // the fifo between two fused stages carries no bulk data
   bytes_per_in_frame = 0;
   rate = 1;
@@ -262,9 +303,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     else rate *= 0.5;
     if (i + 1 < ns && !fuse_[i].on) bytes_per_in_frame += rate * 8.0 * C_;
   }
-  // Keep the fp64 fifos between stages around the size of the Infinity Cache: a push is cut into
-  // time slabs, each slab runs through every stage before the next one starts.
-  const double budget = 192.0 * 1024 * 1024;
+  // Bound the fp64 fifos between stages: a push is cut into time slabs, each slab runs through every stage
+  // before the next one starts.  Measured on the 3-stage 44.1k->192k chain (32 streams x 8 ch): 96 MB slabs 15.0,
+  // 192 MB 15.5, 400 MB 16.6, 1600 MB 17.3 Gsamples/s -- launch size matters more than Infinity-Cache residency.
+  const double budget = (getenv("RSMP_SLAB_MB") ? atof(getenv("RSMP_SLAB_MB")) : 1536.0) * 1024 * 1024;
   slab_frames_ = bytes_per_in_frame > 0 ? size_t(budget / bytes_per_in_frame) : plan_.isamp_max;
   slab_frames_ = std::max<size_t>(slab_frames_, 8192);
   slab_frames_ = std::min<size_t>(slab_frames_, std::max<size_t>(plan_.isamp_max, 1));
@@ -362,6 +404,10 @@ Engine::~Engine()
     if (f.cft) (void)hipFree(f.cft);
     if (f.cfm) (void)hipFree(f.cfm);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
+  }
+  for (PolyMf &m : polymf_) {
+    if (m.cfm) (void)hipFree(m.cfm);
+    if (m.blk) (void)hipFree(m.blk);
   }
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
   if (ev_fused_) (void)hipEventDestroy(ev_fused_);
@@ -617,6 +663,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.two_round = fu.cfm != nullptr;
           pa.KS = fu.KS;
           pa.qb_max = fu.qb_max;
+          pa.clip_lo = 0;
+          pa.clip_hi = 0x7fffffffffffffffLL;
           for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
             if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
           HIP_TRY(launch_fused_prep(pa, fu.blk_dev, stream_));
@@ -645,6 +693,49 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
             ++seam_launches_;
             side_pending_ = true;
           }
+        }
+      } else if (launch && count && polymf_[i].cfm) {
+        int rc = ensure_ring(i + 1, dst_need(wro + count));
+        if (rc) return rc;
+        const PolyMf &pm = polymf_[i];
+        const long long at0 = sp.at0 >> 32, i_begin = wro_before - out_offset, i_end = i_begin + count;
+        const long long q_first = (at0 + i_begin * step) / sp.L, q_last = (at0 + (i_end - 1) * step) / sp.L;
+        for (long long t0 = q_first / pm.Vt, t_end = q_last / pm.Vt + 1; t0 < t_end; t0 += pm.blk_cap) {
+          FusedPrepArgs pa; // per-tile bookkeeping: the closed forms of the fused path with V = Vt, no seam exclusion
+          pa.b_offset = 0;
+          pa.B0 = t0;
+          pa.at0 = at0;
+          pa.V = pm.Vt;
+          pa.polyL = sp.L;
+          pa.step = int(step);
+          pa.n = 1;
+          pa.nblocks = int(std::min<long long>(pm.blk_cap, t_end - t0));
+          pa.two_round = 0;
+          pa.KS = pm.KS;
+          pa.qb_max = 0;
+          pa.clip_lo = i_begin;
+          pa.clip_hi = i_end;
+          for (int k : {0, pa.nblocks - 1})
+            if (fused_block_info(pa, k).K > 32) return kInternal; // 4 column steps x 2 halves x 4 periods
+          HIP_TRY(launch_fused_prep(pa, pm.blk, stream_));
+          PolyMfArgs a;
+          a.cfm = pm.cfm;
+          a.blk = pm.blk;
+          a.B0 = t0;
+          a.at0 = at0;
+          a.out_offset = out_offset;
+          a.in_limit = b.wr[i];
+          a.nblocks = pa.nblocks;
+          a.C = C_;
+          a.Vt = pm.Vt;
+          a.n = sp.n;
+          a.polyL = sp.L;
+          a.step = int(step);
+          a.NGRP = pm.NGRP;
+          const int pi = prof_begin(false);
+          HIP_TRY(launch_polymf(pm.KS, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                                dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_));
+          prof_end(pi);
         }
       } else if (launch && count) {
         int rc = ensure_ring(i + 1, dst_need(wro + count));

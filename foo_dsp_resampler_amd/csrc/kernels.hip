@@ -11,6 +11,7 @@
 // rate/rate_base.h:559-563.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <atomic>
 
 #include "fft_device.hpp"
@@ -39,11 +40,14 @@ template <bool SPLIT> struct LdsCx {
 };
 
 template <int LOG2N, int LOG2P, int LOG2ND>
-__global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyView out, DftArgs a)
+__global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 4 : 1) void dft_kernel(AnyView in, AnyView out, DftArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P, ND = 1 << LOG2ND;
   constexpr int T = N / 16, TF = P / 16, TD = ND / 16;
   constexpr bool SPLIT = LOG2N >= 14;
+  // 8192-point blocks that keep their length: exchanges in two half rounds (70 KB instead of 139 KB of LDS), so two
+  // workgroups share a CU
+  constexpr int XMODE = SPLIT ? 1 : (LOG2N == 13 && LOG2ND == 13) ? 2 : 0;
   constexpr int ROUNDS = SPLIT ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -84,7 +88,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
     }
   }
 
-  fft_regs<LOG2P, -1, SPLIT>(v, tid, fwd_active, a.tw_fwd, lds);
+  fft_regs<LOG2P, -1, (XMODE == 2 && LOG2P < LOG2N) ? 0 : XMODE>(v, tid, fwd_active, a.tw_fwd, lds);
 
   const LdsCx<SPLIT> L{lds};
   if constexpr (LOG2P == LOG2N && LOG2ND == LOG2N) {
@@ -141,7 +145,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void dft_kernel(AnyView in, AnyV
   }
 
   const bool inv_active = tid < TD;
-  fft_regs<LOG2ND, +1, SPLIT>(v, tid, inv_active, a.tw_inv, lds);
+  fft_regs<LOG2ND, +1, XMODE>(v, tid, inv_active, a.tw_inv, lds);
 
   if (inv_active) {
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
@@ -274,7 +278,10 @@ template <int LOG2N, int LOG2P, int LOG2ND>
 static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_bytes = LOG2N >= 14 ? 8 * size_t(N) : 8 * size_t(fft_lds_doubles(LOG2N));
+  constexpr size_t lds_bytes = LOG2N >= 14 ? 8 * size_t(N)
+                               : (LOG2N == 13 && LOG2ND == 13)
+                                   ? std::max(8 * size_t(fft_lds_doubles_halves(13)), LOG2P < LOG2N ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
+                                   : 8 * size_t(fft_lds_doubles(LOG2N));
   static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
   if (!attr_done.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),

@@ -73,12 +73,15 @@ struct FusedPrepArgs {
   long long b_offset, B0, at0; // as in FusedArgs / DftArgs
   int V, polyL, step, n, nblocks;
   int two_round, KS, qb_max;   // matrix-pipe variant: split of the periods over its two LDS images
+  long long clip_lo, clip_hi;  // only outputs with index in [clip_lo, clip_hi) belong to this launch (standalone stage)
 };
 __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, int k)
 {
   const long long b0 = p.b_offset + (p.B0 + k) * (long long)p.V;
   const long long nlo = b0 * p.polyL - p.at0, nhi = (b0 + p.V - p.n + 1) * p.polyL - p.at0;
-  const long long ilo = nlo <= 0 ? 0 : (nlo + p.step - 1) / p.step, ihi = nhi <= 0 ? 0 : (nhi + p.step - 1) / p.step;
+  long long ilo = nlo <= 0 ? 0 : (nlo + p.step - 1) / p.step, ihi = nhi <= 0 ? 0 : (nhi + p.step - 1) / p.step;
+  if (ilo < p.clip_lo) ilo = p.clip_lo;
+  if (ihi > p.clip_hi) ihi = p.clip_hi;
   FusedBlock fb;
   fb.i_lo = ilo;
   fb.cnt = ihi > ilo ? int(ihi - ilo) : 0;
@@ -149,6 +152,20 @@ hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
 bool fused_mfma_supported(int log2n, int log2p, int ksteps);
 hipError_t launch_fused_prep(const FusedPrepArgs &p, FusedBlock *out, hipStream_t st);
+
+// standalone rational polyphase stage on the matrix pipe (polymf.hip)
+struct PolyMfArgs {
+  const double *cfm;     // A operands [16-residue group][k-step][lane], as in FusedArgs
+  const FusedBlock *blk; // per tile: fused_block_info with V = Vt, n = 1, b_offset = 0, clipped to the launch's outputs
+  long long B0;          // first tile of the launch: tile B covers stage-input samples [B*Vt, (B+1)*Vt)
+  long long at0;         // absolute initial clock of the stage, units 1/polyL
+  long long out_offset;  // preload of the destination fifo
+  long long in_limit;    // stage-input samples at absolute index >= in_limit are not written yet: read as zero
+  int nblocks, C, Vt, n, polyL, step, NGRP;
+};
+bool polymf_supported(int ksteps);
+hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                         const F64View &dd, const PolyMfArgs &a, hipStream_t st);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
 hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,
