@@ -23,6 +23,16 @@
 #include <cstdlib>
 #include <cstdio>
 
+// Profiling switches (environment, read once per handle; all zero / unset in production):
+//   RSMP_DBG bit 0 (1): skip the polyphase stage       bit 1 (2): skip the inverse FFT      bit 2 (4): skip the forward FFT
+//            bit 4 (16): compute the polyphase sums but do not store them
+//            bit 5 (32) / 6 (64): matrix-pipe variant, skip round B / round A
+//            bit 9 (512): reuse the first B operands of an item (no further LDS reads)
+//            bit 10 (1024): do not reload A tiles      bit 8 (256): drain all counters at every RSMP_STAMPS stamp
+//   RSMP_STAMPS=1   per-phase cycle sums of wave 0 (s_memtime), printed when the handle closes (intrusive: ~2x slower)
+//   RSMP_LDS_PAD=n  add n bytes of LDS per workgroup (occupancy experiments), RSMP_OCC=1 prints the resulting blocks/CU
+//   RSMP_NO_MFMA / RSMP_NO_FUSE / RSMP_NO_POLYMF / RSMP_NO_SIDE / RSMP_SLAB_MB: engine.cpp
+//
 // twiddles per pass prefetched ahead of the preceding LDS exchange (forward / inverse transform of the MF variant)
 #ifndef RSMP_PFW
 #define RSMP_PFW 15
