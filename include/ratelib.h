@@ -15,46 +15,32 @@
 #include <stddef.h>
 
 /* return codes of every RR_* function; replaces rate/ratelib.h:25-34 (same values) */
-enum RR_error
-{
-    RR_OK = 0,       /* success                                                          */
-    RR_ENOMEM,       /* host or device allocation failed (the alloc handler ran first)   */
-    RR_INTERNAL,     /* a HIP call failed                                                */
-    RR_NULLHANDLE,   /* handle argument was NULL                                         */
-    RR_RATEERROR,    /* kept for ABI compatibility; not produced                         */
-    RR_EXTUNINIT,    /* init_ratelib() has not succeeded, or no HIP device is present    */
-    RR_INVPARAM,     /* bad argument, or a rate ratio outside [1/5644.8, 5644.8]         */
+enum RR_error {
+    RR_OK         = 0, /* success                                                          */
+    RR_ENOMEM     = 1, /* host or device allocation failed (the alloc handler ran first)   */
+    RR_INTERNAL   = 2, /* a HIP call failed                                                */
+    RR_NULLHANDLE = 3, /* handle argument was NULL                                         */
+    RR_RATEERROR  = 4, /* kept for ABI compatibility; not produced                         */
+    RR_EXTUNINIT  = 5, /* init_ratelib() has not succeeded, or no HIP device is present    */
+    RR_INVPARAM   = 6  /* bad argument, or a rate ratio outside [1/5644.8, 5644.8]         */
 };
 
 /* replaces rate/ratelib.h:36-42.  Both qualities run the fp64 chain on the GPU; RR_norm only
  * changes the filter specification (20-bit accuracy, small roll-off) as in rate_base.h:692-695. */
-enum RR_quality
-{
-    RR_best = 0,
-    RR_norm = 1,
-};
+enum RR_quality { RR_best = 0, RR_norm = 1 };
 
 /* replaces rate/ratelib.h:44-49: filter phase response, any value in [0,100] */
-enum RR_phase
-{
-    RR_minimum = 0,
-    RR_linear  = 50,
-    RR_maximum = 100,
-};
+enum RR_phase { RR_minimum = 0, RR_linear = 50, RR_maximum = 100 };
 
 typedef float fb_sample_t; /* rate/ratelib.h:51; foobar2000's audio_sample */
 
 /* replaces rate/ratelib.h:53-63, field for field */
-typedef struct RR_config_tag
-{
-    size_t in_rate;      /* Hz */
-    size_t out_rate;     /* Hz */
-
-    double phase;        /* 0 = minimum ... 50 = linear ... 100 = maximum          */
-    double bandwidth;    /* -3 dB pass-band end, percent of Nyquist (90 ... 99)    */
-    int allow_aliasing;  /* non-zero: let the transition band alias above `bandwidth` */
-
-    enum RR_quality quality;
+typedef struct RR_config_tag {
+    size_t in_rate, out_rate;  /* Hz                                                              */
+    double phase;              /* 0 = minimum ... 50 = linear ... 100 = maximum                   */
+    double bandwidth;          /* -3 dB pass-band end, percent of Nyquist (90 ... 99)             */
+    int allow_aliasing;        /* non-zero: let the transition band alias above `bandwidth`       */
+    enum RR_quality quality;   /* RR_best / RR_norm                                               */
 } RR_config;
 
 typedef struct RR_handle_tag RR_handle; /* opaque; rate/ratelib.h:65 */
@@ -72,11 +58,13 @@ int init_ratelib(void (*alloc_error_handler)(void));
 /* Replaces rate/ratelib.h:74 (rate_uni.c:27-57).  Designs the filters on the host, uploads them and
  * allocates the device fifos.  Unlike the reference, an unsupported ratio returns RR_INVPARAM
  * instead of a half-built handle (rate_base.h:738 ignores the failure). */
-int RR_open(const RR_config *config, int nchannels, RR_handle **const handle);
+int RR_open(const RR_config *config, int nchannels,
+            RR_handle **const handle);
 
 /* Replaces rate/ratelib.h:75 (rate_base.h:571-614): deliver up to osamp ready frames, take isamp
  * input frames, deliver again.  iused / ogen may be NULL. */
-int RR_flow(RR_handle *h, const fb_sample_t *ibuf, fb_sample_t *obuf, size_t isamp, size_t osamp, size_t *iused, size_t *ogen);
+int RR_flow(RR_handle *h, const fb_sample_t *ibuf, fb_sample_t *obuf,
+            size_t isamp, size_t osamp, size_t *iused, size_t *ogen);
 
 /* Replaces rate/ratelib.h:76 (rate_base.h:616-636).  ibuf == NULL or isamp == 0 is a no-op; more
  * than isamp_max = 1048576 * min(1, in/out) frames are silently truncated, as in the reference.
