@@ -72,6 +72,28 @@ const double2 *Engine::twiddles(int log2m)
   return d_tw_[log2m];
 }
 
+const double2 *Engine::twiddles8(int log2m)
+{
+  if (d_tw8_[log2m]) return d_tw8_[log2m];
+  // radix-8 passes with a final radix 8 / 4 / 2: [pass >= 1][r-1][k] = exp(+2 pi i r k / (R Ns)); see fft8_regs
+  std::vector<double2> tab;
+  const int np = (log2m + 2) / 3, rl = (log2m % 3) ? (1 << (log2m % 3)) : 8;
+  long long ns = 8;
+  for (int p = 1; p < np; ++p, ns *= 8) {
+    const int R = p + 1 == np ? rl : 8;
+    for (int r = 1; r < R; ++r)
+      for (long long k = 0; k < ns; ++k) {
+        const long double th = 2.0L * 3.14159265358979323846264338327950288L * (long double)(r * k) / (long double)(R * ns);
+        tab.push_back(make_double2((double)cosl(th), (double)sinl(th)));
+      }
+  }
+  if (tab.empty()) tab.push_back(make_double2(1, 0));
+  void *d = nullptr;
+  if (upload(tab.data(), tab.size() * sizeof(double2), &d) != kOk) return nullptr;
+  d_tw8_[log2m] = static_cast<double2 *>(d);
+  return d_tw8_[log2m];
+}
+
 int Engine::init(const Config &cfg, int nch, int nstreams)
 {
   int rc = make_plan(cfg, plan_);
@@ -389,6 +411,7 @@ Engine::~Engine()
   for (double2 *&g : d_G_) if (g) (void)hipFree(g);
   if (d_poly_) (void)hipFree(d_poly_);
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
+  for (double2 *&t : d_tw8_) if (t) (void)hipFree(t);
   set_profiling(false);
   if (d_stage_) (void)hipFree(d_stage_);
   if (stamps_) {
@@ -576,6 +599,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
         a.tw_fwd = twiddles(log2p);
         a.tw_inv = twiddles(log2nd);
+        a.tw_fwd8 = (log2p >= 6 && log2p <= 12) ? twiddles8(log2p) : nullptr;
+        if (log2p >= 6 && log2p <= 12 && !a.tw_fwd8) return kNoMem;
         a.B0 = B0;
         a.out_offset = out_offset;
         a.nblocks = nblocks;

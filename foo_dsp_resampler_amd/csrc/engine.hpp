@@ -83,6 +83,7 @@ private:
   void note_input(Book &b, size_t n) const;
   int upload(const void *src, size_t bytes, void **dst);
   const double2 *twiddles(int log2m);
+  const double2 *twiddles8(int log2m);
   void free_garbage();
 
   ChainPlan plan_;
@@ -102,6 +103,7 @@ private:
   double2 *d_G_[2] = {nullptr, nullptr};
   double *d_poly_ = nullptr;
   double2 *d_tw_[20] = {};
+  double2 *d_tw8_[20] = {}; // 8-points-per-thread plans (fft8_regs)
   // staging for host pushes / drains
   // GPU block length of each dft stage: the reference's N, or 16384 when that is larger ("decoupled":
   // availability still follows the reference's N, the kernels run their own absolute-anchored blocks)

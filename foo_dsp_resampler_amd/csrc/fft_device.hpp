@@ -274,4 +274,78 @@ __device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, con
   if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4, 0, 1>(v, tid, active, tw + 15 * R0 * 17, lds, wa, wb, tw);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 8 points per thread: an M-point transform on T8 = M/8 threads (used where a transform has half the points of
+// the workgroup's main one, so that all waves take part: thread `tid` owns x[tid + s*T8], s = 0..7, on entry and
+// on exit).  Passes are radix 8 with a final radix 8, 4 or 2 (log2 M = 3a + b); twiddle table layout
+// [pass >= 1][r-1][k] with entries exp(+2 pi i r k / (R Ns)), see Engine::twiddles8.
+constexpr int fft8_num_passes(int log2m) { return (log2m + 2) / 3; }
+constexpr int fft8_last_radix(int log2m) { return (log2m % 3) ? (1 << (log2m % 3)) : 8; }
+constexpr int fft8_twiddle_count(int log2m)
+{
+  int n = 0, ns = 8;
+  for (int p = 1; p < fft8_num_passes(log2m); ++p) {
+    const int r = p + 1 == fft8_num_passes(log2m) ? fft8_last_radix(log2m) : 8;
+    n += (r - 1) * ns;
+    ns *= 8;
+  }
+  return n;
+}
+constexpr int fft8_lds_doubles(int log2m) { return 2 * ((1 << log2m) + (1 << log2m) / 8); } // first exchange padded
+
+template <int LOG2M, int R, int NS, int DIR, bool LAST>
+__device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
+{
+  constexpr int T8 = (1 << LOG2M) / 8, NB = 8 / R;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    c64 b[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) b[r] = u[t + NB * r];
+    if (NS > 1) {
+      const int k = (tid + t * T8) & (NS - 1);
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        const double2 w = tw[(r - 1) * NS + k];
+        b[r] = DIR > 0 ? cmul(b[r], c64{w.x, w.y}) : cmulc(b[r], c64{w.x, w.y});
+      }
+    }
+    Bfly<R, DIR>::run(b);
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[t + NB * r] = b[r];
+  }
+  if (!LAST) {
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    constexpr int PADR = NS == 1 ? 8 : 1; // the first pass scatters with a lane stride of 8 elements
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int j = tid + t * T8, k = j & (NS - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) l2[lds_phys<PADR>((j - k) * R + k + r * NS)] = make_double2(u[t + NB * r].x, u[t + NB * r].y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const double2 q = l2[lds_phys<PADR>(tid + s * T8)];
+      u[s] = {q.x, q.y};
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOG2M, int DIR>
+__device__ __forceinline__ void fft8_regs(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
+{
+  constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M);
+  static_assert(NP >= 2 && NP <= 4, "fft8_regs: 64 <= M <= 4096");
+  fft8_pass<LOG2M, 8, 1, DIR, false>(u, tid, tw, lds);
+  if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true>(u, tid, tw, lds);
+  if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false>(u, tid, tw, lds);
+  if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true>(u, tid, tw + 7 * 8, lds);
+  if constexpr (NP == 4) {
+    fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds);
+    fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds);
+  }
+}
+
 } // namespace rsmp

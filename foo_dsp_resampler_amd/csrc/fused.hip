@@ -33,6 +33,12 @@
 //   RSMP_LDS_PAD=n  add n bytes of LDS per workgroup (occupancy experiments), RSMP_OCC=1 prints the resulting blocks/CU
 //   RSMP_NO_MFMA / RSMP_NO_FUSE / RSMP_NO_POLYMF / RSMP_NO_SIDE / RSMP_SLAB_MB: engine.cpp
 //
+// RSMP_FWD8=1: L = 2 forward transform on all four waves, 8 points per thread (fft8_regs), no replication exchange.
+// Parity-green; the FFT part of the kernel gets 21 % faster (1.71 -> 1.36 ms with the polyphase stage skipped) but the
+// whole kernel does not (2.67 vs 2.63 ms): the polyphase phase loses the FFT phases it used to overlap with.
+#ifndef RSMP_FWD8
+#define RSMP_FWD8 0
+#endif
 // twiddles per pass prefetched ahead of the preceding LDS exchange (forward / inverse transform of the MF variant)
 #ifndef RSMP_PFW
 #define RSMP_PFW 15
@@ -107,7 +113,12 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
     const bool hasb = cb < a.d.C;
 
     // ---------------------------------------------------------------- load the block (fp32 -> fp64)
+    // L = 2 in the matrix-pipe variant: the forward transform has half the points of the inverse one and runs
+    // 8 points per thread on all waves (fft8_regs); a thread then already holds the 8 distinct spectrum values
+    // Zp[tid + (s & 7) * T] its 16 inverse-transform inputs need, so the replication exchange disappears
+    constexpr bool FWD8 = MF && (LOG2N - LOG2P == 1) && RSMP_FWD8;
     c64 v[16];
+    c64 u8[8];
     {
       const long long e0 = B * a.d.q;
       bool fast = false;
@@ -126,7 +137,23 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
           p2 = reinterpret_cast<const float2 *>(p);
         }
       }
-      if (fwd_active) {
+      if constexpr (FWD8) { // every thread takes 8 points of the P-point forward transform: x[tid + s*T], T = P/8
+        if (fast) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const float2 f = p2[(tid + s * T) * fstride];
+            u8[s] = {(double)f.x, (double)f.y};
+          }
+        } else {
+          const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const long long e = e0 + tid + s * T;
+            u8[s].x = fifo_get(ia, e);
+            u8[s].y = hasb ? fifo_get(ib, e) : 0.0;
+          }
+        }
+      } else if (fwd_active) {
         if (fast) {
 #pragma unroll
           for (int s = 0; s < 16; ++s) {
@@ -147,9 +174,21 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
 
     RSMP_STAMP(0)
     // ---------------------------------------------------------------- FFT-FIR (as dft_kernel)
+    if constexpr (FWD8) {
+      double2 g[16]; // in flight during the whole forward transform (32 + 64 registers live)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
+      if (!(a.dbg & 4)) fft8_regs<LOG2P, -1>(u8, tid, a.d.tw_fwd8, lds);
+      RSMP_STAMP(1)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) v[s] = cmul(u8[s & 7], c64{g[s].x, g[s].y});
+      __syncthreads(); // the inverse transform's exchange reuses the LDS the forward one just read
+    } else {
     if (!(a.dbg & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0, MF ? RSMP_PFW : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
     RSMP_STAMP(1)
-    if constexpr (LOG2P < LOG2N) {
+    }
+    if constexpr (FWD8) {
+    } else if constexpr (LOG2P < LOG2N) {
       double2 g[16]; // issued before the exchange so the L2 latency overlaps it
 #pragma unroll
       for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
@@ -557,7 +596,7 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
   size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
   if (MF) { // half-round exchanges for 4096-point transforms, two-round sample image (fused_kernel, MF part)
     lds_bytes = 8 * size_t(fft_lds_doubles_halves(LOG2N));
-    if (LOG2P < LOG2N) lds_bytes = std::max(lds_bytes, 8 * size_t(fft_lds_doubles(LOG2P)));
+    if (LOG2P < LOG2N) lds_bytes = std::max(lds_bytes, 8 * size_t(std::max(fft_lds_doubles(LOG2P), fft8_lds_doubles(LOG2P))));
     lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
   }
   lds_bytes += lds_pad;
