@@ -355,7 +355,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
           for (int u = 0; u < MAXCS; ++u) {
             if (u < pend_n) {
               const int ib = pend_ib + u * 4 * pl;
-              if (((pend_allv >> u) & 1) || (ib >= fb.irel_lo && ib < pend_hi)) {
+              if ((((pend_allv >> u) & 1) || (ib >= fb.irel_lo && ib < pend_hi))) {
                 const int orel = ib - fb.irel_lo;
                 if (FAST) {
                   *reinterpret_cast<float2 *>(obytes + (pend_off + u * period4_bytes)) = make_float2((float)pA[u], (float)pB[u]);
