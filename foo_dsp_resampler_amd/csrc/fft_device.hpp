@@ -294,9 +294,10 @@ constexpr int fft8_twiddle_count(int log2m)
 constexpr int fft8_lds_doubles(int log2m) { return 2 * ((1 << log2m) + (1 << log2m) / 8); } // first exchange padded
 
 template <int LOG2M, int R, int NS, int DIR, bool LAST>
-__device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
+__device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds, bool active = true)
 {
   constexpr int T8 = (1 << LOG2M) / 8, NB = 8 / R;
+  if (active) {
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
     c64 b[R];
@@ -314,38 +315,49 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
 #pragma unroll
     for (int r = 0; r < R; ++r) u[t + NB * r] = b[r];
   }
+  }
   if (!LAST) {
     double2 *l2 = reinterpret_cast<double2 *>(lds);
     constexpr int PADR = NS == 1 ? 8 : 1; // the first pass scatters with a lane stride of 8 elements
+    if (active) {
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      const int j = tid + t * T8, k = j & (NS - 1);
+      for (int t = 0; t < NB; ++t) {
+        const int j = tid + t * T8, k = j & (NS - 1);
 #pragma unroll
-      for (int r = 0; r < R; ++r) l2[lds_phys<PADR>((j - k) * R + k + r * NS)] = make_double2(u[t + NB * r].x, u[t + NB * r].y);
+        for (int r = 0; r < R; ++r) l2[lds_phys<PADR>((j - k) * R + k + r * NS)] = make_double2(u[t + NB * r].x, u[t + NB * r].y);
+      }
     }
     __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const double2 q = l2[lds_phys<PADR>(tid + s * T8)];
-      u[s] = {q.x, q.y};
+      for (int s = 0; s < 8; ++s) {
+        const double2 q = l2[lds_phys<PADR>(tid + s * T8)];
+        u[s] = {q.x, q.y};
+      }
     }
     __syncthreads();
   }
 }
 
+// `active`: threads that hold points (tid < M/8); every thread of the workgroup must call (barriers)
 template <int LOG2M, int DIR>
-__device__ __forceinline__ void fft8_regs(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
+__device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M);
   static_assert(NP >= 2 && NP <= 4, "fft8_regs: 64 <= M <= 4096");
-  fft8_pass<LOG2M, 8, 1, DIR, false>(u, tid, tw, lds);
-  if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true>(u, tid, tw, lds);
-  if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false>(u, tid, tw, lds);
-  if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true>(u, tid, tw + 7 * 8, lds);
+  fft8_pass<LOG2M, 8, 1, DIR, false>(u, tid, tw, lds, active);
+  if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true>(u, tid, tw, lds, active);
+  if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false>(u, tid, tw, lds, active);
+  if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true>(u, tid, tw + 7 * 8, lds, active);
   if constexpr (NP == 4) {
-    fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds);
-    fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds);
+    fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds, active);
+    fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
   }
+}
+template <int LOG2M, int DIR>
+__device__ __forceinline__ void fft8_regs(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
+{
+  fft8_regs_masked<LOG2M, DIR>(u, tid, true, tw, lds);
 }
 
 } // namespace rsmp

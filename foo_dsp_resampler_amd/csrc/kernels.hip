@@ -61,6 +61,24 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
 
   c64 v[16];
   const bool fwd_active = tid < TF;
+  // x4 upsampling in the frequency domain on up to 8192-point blocks: the forward transform has a quarter of the
+  // points; run it 8 points per thread on twice as many threads (fft8_regs) -- a thread tid < 2*TF then owns
+  // Zp[tid + s*2*TF], and the inverse transform's thread t needs Zp[(t mod T) + T*j], j < 4: its own even slots for
+  // t < 2*TF, the odd slots of thread t - 2*TF otherwise
+  constexpr bool F8 = !SPLIT && LOG2N - LOG2P == 2 && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 12;
+  c64 u8[8];
+  if constexpr (F8) {
+    if (tid < 2 * TF) {
+      const long long base = B * a.q;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const long long e = base + tid + s * 2 * TF;
+        const bool have = e < a.in_limit;
+        u8[s].x = have ? fifo_get(ia, e) : 0.0;
+        u8[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
+      }
+    }
+  } else
   if (fwd_active) {
     if (LOG2P < LOG2N || a.L == 1) {
       const long long base = B * a.q;
@@ -90,10 +108,43 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
     }
   }
 
+  if constexpr (F8) {
+    // (all threads take part in the barriers of fft8_regs; threads >= 2*TF carry zeros)
+    if (tid >= 2 * TF) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) u8[s] = {0.0, 0.0};
+    }
+    fft8_regs_masked<LOG2P, -1>(u8, tid, tid < 2 * TF, a.tw_fwd8, lds);
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    if (tid < 2 * TF) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l2[tid + j * 2 * TF] = make_double2(u8[2 * j + 1].x, u8[2 * j + 1].y);
+    }
+    __syncthreads();
+    c64 z[4];
+    if (tid < 2 * TF) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = u8[2 * j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double2 q = l2[tid - 2 * TF + j * 2 * TF];
+        z[j] = {q.x, q.y};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 g = a.G[tid + s * T];
+      v[s] = cmul(z[s & 3], c64{g.x, g.y});
+    }
+  } else {
   fft_regs<LOG2P, -1, (XMODE == 2 && LOG2P < LOG2N) ? 0 : XMODE>(v, tid, fwd_active, a.tw_fwd, lds);
+  }
 
   const LdsCx<SPLIT> L{lds};
-  if constexpr (LOG2P == LOG2N && LOG2ND == LOG2N) {
+  if constexpr (F8) {
+  } else if constexpr (LOG2P == LOG2N && LOG2ND == LOG2N) {
     // same thread/slot layout on both sides: multiply in registers
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
