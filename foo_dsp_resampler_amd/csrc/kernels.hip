@@ -65,14 +65,16 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   // points; run it 8 points per thread on twice as many threads (fft8_regs) -- a thread tid < 2*TF then owns
   // Zp[tid + s*2*TF], and the inverse transform's thread t needs Zp[(t mod T) + T*j], j < 4: its own even slots for
   // t < 2*TF, the odd slots of thread t - 2*TF otherwise
-  constexpr bool F8 = !SPLIT && LOG2N - LOG2P == 2 && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 12;
+  // (with x2 upsampling the same plan uses ALL threads, and a thread ends up with exactly the 8 values it needs)
+  constexpr bool F8 = !SPLIT && (LOG2N - LOG2P == 2 || LOG2N - LOG2P == 1) && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 12;
+  constexpr int T8 = P / 8; // threads of the 8-points-per-thread forward transform
   c64 u8[8];
   if constexpr (F8) {
-    if (tid < 2 * TF) {
+    if (tid < T8) {
       const long long base = B * a.q;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const long long e = base + tid + s * 2 * TF;
+        const long long e = base + tid + s * T8;
         const bool have = e < a.in_limit;
         u8[s].x = have ? fifo_get(ia, e) : 0.0;
         u8[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
@@ -109,34 +111,43 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   }
 
   if constexpr (F8) {
-    // (all threads take part in the barriers of fft8_regs; threads >= 2*TF carry zeros)
-    if (tid >= 2 * TF) {
+    // (all threads take part in the barriers of fft8_regs; threads >= T8 carry zeros)
+    if (tid >= T8) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) u8[s] = {0.0, 0.0};
     }
-    fft8_regs_masked<LOG2P, -1>(u8, tid, tid < 2 * TF, a.tw_fwd8, lds);
-    double2 *l2 = reinterpret_cast<double2 *>(lds);
-    if (tid < 2 * TF) {
+    fft8_regs_masked<LOG2P, -1>(u8, tid, tid < T8, a.tw_fwd8, lds);
+    if constexpr (LOG2N - LOG2P == 1) { // T8 == T: Z[tid + s*T] = Zp[tid + (s & 7)*T] is already here
+      __syncthreads(); // the inverse transform's exchange reuses the LDS the forward one just read
 #pragma unroll
-      for (int j = 0; j < 4; ++j) l2[tid + j * 2 * TF] = make_double2(u8[2 * j + 1].x, u8[2 * j + 1].y);
-    }
-    __syncthreads();
-    c64 z[4];
-    if (tid < 2 * TF) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) z[j] = u8[2 * j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double2 q = l2[tid - 2 * TF + j * 2 * TF];
-        z[j] = {q.x, q.y};
+      for (int s = 0; s < 16; ++s) {
+        const double2 g = a.G[tid + s * T];
+        v[s] = cmul(u8[s & 7], c64{g.x, g.y});
       }
-    }
-    __syncthreads();
+    } else {
+      double2 *l2 = reinterpret_cast<double2 *>(lds);
+      if (tid < T8) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const double2 g = a.G[tid + s * T];
-      v[s] = cmul(z[s & 3], c64{g.x, g.y});
+        for (int j = 0; j < 4; ++j) l2[tid + j * T8] = make_double2(u8[2 * j + 1].x, u8[2 * j + 1].y);
+      }
+      __syncthreads();
+      c64 z[4];
+      if (tid < T8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = u8[2 * j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double2 q = l2[tid - T8 + j * T8];
+          z[j] = {q.x, q.y};
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double2 g = a.G[tid + s * T];
+        v[s] = cmul(z[s & 3], c64{g.x, g.y});
+      }
     }
   } else {
   fft_regs<LOG2P, -1, (XMODE == 2 && LOG2P < LOG2N) ? 0 : XMODE>(v, tid, fwd_active, a.tw_fwd, lds);
@@ -331,10 +342,11 @@ template <int LOG2N, int LOG2P, int LOG2ND>
 static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_bytes = LOG2N >= 14 ? 8 * size_t(N)
+  constexpr size_t lds_fwd8 = (LOG2N < 14 && LOG2ND == LOG2N && LOG2P < LOG2N && LOG2P >= 6 && LOG2P <= 12) ? 8 * size_t(fft8_lds_doubles(LOG2P)) : 0;
+  constexpr size_t lds_bytes = std::max(lds_fwd8, LOG2N >= 14 ? 8 * size_t(N)
                                : (LOG2N == 13 && LOG2ND == 13)
                                    ? std::max(8 * size_t(fft_lds_doubles_halves(13)), LOG2P < LOG2N ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
-                                   : 8 * size_t(fft_lds_doubles(LOG2N));
+                                   : 8 * size_t(fft_lds_doubles(LOG2N)));
   static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
   if (!attr_done.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),
