@@ -601,6 +601,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.tw_inv = twiddles(log2nd);
         a.tw_fwd8 = (log2p >= 6 && log2p <= 12) ? twiddles8(log2p) : nullptr;
         if (log2p >= 6 && log2p <= 12 && !a.tw_fwd8) return kNoMem;
+        a.tw_inv8 = (log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
+        if (log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
         a.B0 = B0;
         a.out_offset = out_offset;
         a.nblocks = nblocks;

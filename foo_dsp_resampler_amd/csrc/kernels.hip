@@ -68,6 +68,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   // (with x2 upsampling the same plan uses ALL threads, and a thread ends up with exactly the 8 values it needs)
   constexpr bool F8 = !SPLIT && (LOG2N - LOG2P == 2 || LOG2N - LOG2P == 1) && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 12;
   constexpr int T8 = P / 8; // threads of the 8-points-per-thread forward transform
+  // Frequency-domain decimation by 2 (same block length in, half out): the kept bins k' = t + s'*T (s' < 8) of thread t
+  // are its own slots 0-3 and 12-15 of the N-point spectrum, so no exchange is needed, and the ND-point inverse
+  // transform runs 8 points per thread on ALL threads instead of 16 points on half of them.
+  constexpr bool D8 = !SPLIT && LOG2P == LOG2N && LOG2ND == LOG2N - 1 && LOG2ND >= 6 && LOG2ND <= 12;
   c64 u8[8];
   if constexpr (F8) {
     if (tid < T8) {
@@ -188,6 +192,28 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
     for (int s = 0; s < 16; ++s) {
       const double2 g = a.G[tid + s * T];
       v[s] = cmul(v[s], c64{g.x, g.y});
+    }
+    if constexpr (D8) {
+      c64 d8[8];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        d8[s] = v[s];
+        d8[s + 4] = v[s + 12];
+      }
+      if (tid == 0) d8[4] = {0.5 * (v[4].x + v[12].x), 0.5 * (v[4].y + v[12].y)}; // new Nyquist bin: mean of its two images
+      fft8_regs<LOG2ND, +1>(d8, tid, a.tw_inv8, lds);
+      const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
+      const long long o0 = B * a.Vout;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int n = tid + s * T;
+        const long long o = o0 + n;
+        if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
+          fifo_put(oa, a.out_offset + o, d8[s].x);
+          if (hasb) fifo_put(ob, a.out_offset + o, d8[s].y);
+        }
+      }
+      return;
     }
     c64 nyq = {0.0, 0.0};
 #pragma unroll

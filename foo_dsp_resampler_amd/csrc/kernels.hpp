@@ -35,7 +35,8 @@ struct DftArgs {
   const double2 *G;      // N entries: DFT_N(L * h_placed) / N, natural order, e^{-i} convention
   const double2 *tw_fwd; // twiddle table for the forward size P
   const double2 *tw_inv; // twiddle table for the inverse size Nd
-  const double2 *tw_fwd8; // forward size P, 8-points-per-thread plan (fft8_regs); used by the fused L = 2 kernel
+  const double2 *tw_fwd8; // forward size P, 8-points-per-thread plan (fft8_regs)
+  const double2 *tw_inv8; // inverse size Nd, 8-points-per-thread plan (frequency-domain decimation by 2)
   long long B0;          // absolute index of the first block of this launch
   long long out_offset;  // preload of the destination fifo (absolute index of stage output 0)
   int nblocks;
