@@ -336,17 +336,29 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_kernel(AnyView 
 
 // ---------------------------------------------------------------------------------------------
 // Half-band stage: y[i] = .5 x[c] + sum_k coef[k] (x[c-(2k+1)] + x[c+(2k+1)]),  c = rd + pre + 2 i
+// One workgroup = a tile of kHalfTile outputs of one channel.  Its 2*tile + 4*ncoef input samples are staged in LDS
+// de-interleaved by parity (the centre taps live on one parity, all other taps on the other), so that consecutive
+// lanes read consecutive 8-byte elements; sums are formed in the order of the reference's loop.
 // ---------------------------------------------------------------------------------------------
+constexpr int kHalfTile = 2048;
 __global__ __launch_bounds__(256) void half_kernel(AnyView in, AnyView out, HalfArgs a)
 {
-  const int c = blockIdx.y;
+  __shared__ double plane[2][kHalfTile + 32]; // [parity relative to the window start][index / 2]
+  const int tid = threadIdx.x, c = blockIdx.y;
   const ChanRef src = chan_ref(in, c), dst = chan_ref(out, c);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (long long)gridDim.x * 256) {
-    const long long ctr = a.rd + a.pre + 2 * i;
-    double sum = fifo_get(src, ctr) * 0.5;
-    for (int k = 0; k < a.ncoef; ++k)
-      sum += (fifo_get(src, ctr - (2 * k + 1)) + fifo_get(src, ctr + (2 * k + 1))) * a.coef[k];
-    fifo_put(dst, a.out_abs + i, sum);
+  const long long i0 = (long long)blockIdx.x * kHalfTile;
+  const int cnt = (int)min((long long)kHalfTile, a.count - i0);
+  const int reach = 2 * a.ncoef - 1;                       // farthest tap from the centre
+  const long long w0 = a.rd + a.pre + 2 * i0 - reach - 1;  // window start: centre of output 0 sits at w0 + reach + 1
+  const int wlen = 2 * cnt + 2 * reach + 1;                // ... so centres have the parity of (reach + 1) = even
+  for (int i = tid; i < wlen; i += 256) plane[i & 1][i >> 1] = fifo_get(src, w0 + i);
+  __syncthreads();
+  const int half_reach = a.ncoef;                          // (reach + 1) / 2: centre u sits at even-plane index u + ncoef
+  for (int u = tid; u < cnt; u += 256) {
+    double sum = plane[0][u + half_reach] * 0.5;
+    // tap at centre -+ (2k+1): window offset 2u + reach + 1 -+ (2k+1), odd -> odd plane index u + ncoef - 1 - k / u + ncoef + k
+    for (int k = 0; k < a.ncoef; ++k) sum += (plane[1][u + half_reach - 1 - k] + plane[1][u + half_reach + k]) * a.coef[k];
+    fifo_put(dst, a.out_abs + i0 + u, sum);
   }
 }
 
@@ -445,9 +457,9 @@ hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64V
                        const F64View &dd, const HalfArgs &a, hipStream_t st)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
-  long long blocks = (a.count + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  dim3 grid((unsigned)blocks, a.C), block(256);
+  const long long tiles = (a.count + kHalfTile - 1) / kHalfTile;
+  if (a.ncoef > 13) return hipErrorInvalidValue; // window margin of the LDS planes
+  dim3 grid((unsigned)tiles, a.C), block(256);
   hipLaunchKernelGGL(half_kernel, grid, block, 0, st, in, out, a);
   return hipGetLastError();
 }
