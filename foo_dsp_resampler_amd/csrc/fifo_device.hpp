@@ -65,6 +65,66 @@ __device__ __forceinline__ void fifo_put(const ChanRef &r, long long a, double v
 }
 
 
+// Direct addressing of `len` consecutive samples of channel pair (2*pair, 2*pair+1) starting at absolute index a0,
+// when they lie contiguously in one buffer: kind 1 = float32 frames with the two channels side by side (one 8-byte
+// word per sample), kind 2 = the two planar fp64 rings, kind 0 = not contiguous (use fifo_get / fifo_put).
+struct PairSpan {
+  int kind;
+  float2 *p2;
+  long long fstride; // float2 elements between consecutive frames
+  double *pa, *pb;
+  bool hasb;
+  __device__ __forceinline__ void get(int i, double &x, double &y) const
+  {
+    if (kind == 1) {
+      const float2 f = p2[i * fstride];
+      x = (double)f.x;
+      y = (double)f.y;
+    } else {
+      x = pa[i];
+      y = hasb ? pb[i] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void put(int i, double x, double y) const
+  {
+    if (kind == 1) p2[i * fstride] = make_float2((float)x, (float)y);
+    else {
+      pa[i] = x;
+      if (hasb) pb[i] = y;
+    }
+  }
+};
+
+__device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len)
+{
+  PairSpan r;
+  r.kind = 0;
+  r.p2 = nullptr;
+  r.fstride = 1;
+  r.pa = r.pb = nullptr;
+  r.hasb = hasb;
+  if (v.is_f32) {
+    if (hasb && !(v.f.nch & 1)) {
+      const int hp = v.f.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+      float *p = nullptr;
+      if (v.f.ext && a0 >= v.f.ext_begin && a0 + len <= v.f.ext_end)
+        p = v.f.ext + strm * v.f.ext_stream_stride + (a0 - v.f.ext_begin) * v.f.nch + 2 * pin;
+      else if ((!v.f.ext || a0 + len <= v.f.ext_begin || a0 >= v.f.ext_end) && (a0 & v.f.ring_mask) + len <= v.f.ring_mask + 1)
+        p = v.f.ring + strm * v.f.ring_stream_stride + (a0 & v.f.ring_mask) * v.f.nch + 2 * pin;
+      if (p && (reinterpret_cast<unsigned long long>(p) & 7) == 0) {
+        r.kind = 1;
+        r.p2 = reinterpret_cast<float2 *>(p);
+        r.fstride = hp;
+      }
+    }
+  } else if ((a0 & v.d.mask) + len <= v.d.mask + 1) {
+    r.kind = 2;
+    r.pa = v.d.ring + (long long)(2 * pair) * v.d.chan_stride + (a0 & v.d.mask);
+    r.pb = hasb ? r.pa + v.d.chan_stride : r.pa;
+  }
+  return r;
+}
+
 inline AnyView make_view(bool is_f32, const F32View &f, const F64View &d)
 {
   AnyView v;

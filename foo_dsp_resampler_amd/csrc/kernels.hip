@@ -76,24 +76,36 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   if constexpr (F8) {
     if (tid < T8) {
       const long long base = B * a.q;
+      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, blockIdx.y, hasb, base, P) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+      if (sp.kind) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const long long e = base + tid + s * T8;
-        const bool have = e < a.in_limit;
-        u8[s].x = have ? fifo_get(ia, e) : 0.0;
-        u8[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
+        for (int s = 0; s < 8; ++s) sp.get(tid + s * T8, u8[s].x, u8[s].y);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const long long e = base + tid + s * T8;
+          const bool have = e < a.in_limit;
+          u8[s].x = have ? fifo_get(ia, e) : 0.0;
+          u8[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
+        }
       }
     }
   } else
   if (fwd_active) {
     if (LOG2P < LOG2N || a.L == 1) {
       const long long base = B * a.q;
+      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, blockIdx.y, hasb, base, P) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+      if (sp.kind) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const long long e = base + tid + s * TF;
-        const bool have = e < a.in_limit;
-        v[s].x = have ? fifo_get(ia, e) : 0.0;
-        v[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
+        for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const long long e = base + tid + s * TF;
+          const bool have = e < a.in_limit;
+          v[s].x = have ? fifo_get(ia, e) : 0.0;
+          v[s].y = have && hasb ? fifo_get(ib, e) : 0.0;
+        }
       }
     } else { // time-domain zero stuffing (dft_filter.h:109-115) in absolute coordinates
       const long long U = B * a.V;
@@ -204,11 +216,15 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
       fft8_regs<LOG2ND, +1>(d8, tid, a.tw_inv8, lds);
       const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
       const long long o0 = B * a.Vout;
+      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, blockIdx.y, hasb, a.out_offset + o0, a.Vout)
+                                                                       : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int n = tid + s * T;
         const long long o = o0 + n;
-        if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
+        if (so.kind) {
+          if (n < a.Vout) so.put(n, d8[s].x, d8[s].y);
+        } else if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
           fifo_put(oa, a.out_offset + o, d8[s].x);
           if (hasb) fifo_put(ob, a.out_offset + o, d8[s].y);
         }
@@ -241,11 +257,15 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
     if (a.M == 1) {
       const long long o0 = B * a.Vout;
+      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, blockIdx.y, hasb, a.out_offset + o0, a.Vout)
+                                                                       : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int n = tid + s * TD;
         const long long o = o0 + n;
-        if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
+        if (so.kind) {
+          if (n < a.Vout) so.put(n, v[s].x, v[s].y);
+        } else if (n < a.Vout && o >= a.clip_lo && o < a.clip_hi) {
           fifo_put(oa, a.out_offset + o, v[s].x);
           if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
         }
