@@ -161,12 +161,18 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
             v[s] = {(double)f.x, (double)f.y};
           }
         } else {
-          const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+          const PairSpan sp = in.is_f32 ? PairSpan{0, nullptr, 1, nullptr, nullptr, hasb} : pair_span(in, pair, hasb, e0, P);
+          if (sp.kind) { // planar fp64 rings (the producer is another stage), block contiguous in both
 #pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            const long long e = e0 + tid + s * TF;
-            v[s].x = fifo_get(ia, e);
-            v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+            for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
+          } else {
+            const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+              const long long e = e0 + tid + s * TF;
+              v[s].x = fifo_get(ia, e);
+              v[s].y = hasb ? fifo_get(ib, e) : 0.0;
+            }
           }
         }
       }

@@ -32,11 +32,20 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   const int W = a.Vt + a.n + 4; // samples any stored output of this tile can touch
 
   { // stage the window; positions the producer has not written yet read as zero (only unstored outputs see them)
-    const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
-    for (int i = tid; i < W; i += 256) {
-      const long long e = b0 + i;
-      const bool have = e < a.in_limit;
-      smp[i] = make_double2(have ? fifo_get(ia, e) : 0.0, have && hasb ? fifo_get(ib, e) : 0.0);
+    const PairSpan sp = b0 + W <= a.in_limit ? pair_span(in, pair, hasb, b0, W) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+    if (sp.kind) {
+      for (int i = tid; i < W; i += 256) {
+        double x, y;
+        sp.get(i, x, y);
+        smp[i] = make_double2(x, y);
+      }
+    } else {
+      const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
+      for (int i = tid; i < W; i += 256) {
+        const long long e = b0 + i;
+        const bool have = e < a.in_limit;
+        smp[i] = make_double2(have ? fifo_get(ia, e) : 0.0, have && hasb ? fifo_get(ib, e) : 0.0);
+      }
     }
     if (tid < kPmPad) {
       smp[tid - kPmPad] = make_double2(0.0, 0.0);
