@@ -792,6 +792,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.tile = tile;
         a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
         a.tab_lds = tab_lds;
+        a.coop = sp.order >= 1 && sp.n % 8 == 0 && !getenv("RSMP_NO_POLYCOOP");
         const int pi = prof_begin(false);
         HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                             src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,

@@ -354,6 +354,58 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_kernel(AnyView 
   }
 }
 
+// Interpolated polyphase stage (orders 1-3), cooperative variant.  An output's coefficients are one contiguous row of
+// n*(ORDER+1) doubles (768 B at Best), a different row for every output; with one output per lane each 8-byte load
+// instruction touches 64 cache lines.  Here 8 lanes share an output: lane l takes taps [l*n/8, (l+1)*n/8), i.e. a
+// contiguous n/8*(ORDER+1)-double piece of the row (16-byte loads, 8 lanes = one run of the row), and the 8 partial sums
+// are combined with three DPP/shuffle steps -- north_star's "per-phase tap products reduced across the wavefront".
+// (Summation order differs from the reference's sequential loop by that tree: results agree to fp64 rounding.)
+template <int ORDER> __global__ __launch_bounds__(256) void poly_coop_kernel(AnyView in, AnyView out, PolyArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double win[];
+  const int tid = threadIdx.x, c = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * a.tile;
+  const int cnt = (int)min((long long)a.tile, a.count - i0);
+  const ChanRef src = chan_ref(in, c), dst = chan_ref(out, c);
+  const long long A0 = a.at + i0 * a.step, A1 = a.at + (i0 + cnt - 1) * a.step;
+  const long long q0 = A0 >> 32, q1 = A1 >> 32;
+  const int wlen = (int)(q1 - q0) + a.n;
+  for (int i = tid; i < wlen; i += 256) win[i] = fifo_get(src, a.rd + q0 + i);
+  __syncthreads();
+
+  const int sub = tid & 7, tpl = a.n >> 3; // lane within its output's group of 8; taps per lane
+  for (int u0 = 0; u0 < cnt; u0 += 32) {  // 32 outputs per pass of the workgroup
+    const int u = u0 + (tid >> 3);
+    const bool live = u < cnt;
+    const long long A = a.at + (i0 + (live ? u : 0)) * a.step;
+    const unsigned frac = (unsigned)A;
+    const int ph = (int)(frac >> (32 - a.phase_bits));
+    const double t = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
+    const double *cf = a.tab + ((long long)ph * a.n + sub * tpl) * (ORDER + 1);
+    const double *x = win + ((A >> 32) - q0) + sub * tpl;
+    double sum = 0.0;
+    for (int j = 0; j < tpl; ++j) {
+      double w;
+      if constexpr (ORDER == 3) {
+        const double2 c01 = *reinterpret_cast<const double2 *>(cf + 4 * j), c23 = *reinterpret_cast<const double2 *>(cf + 4 * j + 2);
+        w = fma(fma(fma(c01.x, t, c01.y), t, c23.x), t, c23.y);
+      } else if constexpr (ORDER == 1) {
+        const double2 c01 = *reinterpret_cast<const double2 *>(cf + 2 * j);
+        w = fma(c01.x, t, c01.y);
+      } else {
+        w = cf[j * (ORDER + 1)];
+#pragma unroll
+        for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[j * (ORDER + 1) + o]);
+      }
+      sum = fma(w, x[j], sum);
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    if (live && sub == 0) fifo_put(dst, a.out_abs + i0 + u, sum);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Half-band stage: y[i] = .5 x[c] + sum_k coef[k] (x[c-(2k+1)] + x[c+(2k+1)]),  c = rd + pre + 2 i
 // One workgroup = a tile of kHalfTile outputs of one channel.  Its 2*tile + 4*ncoef input samples are staged in LDS
@@ -451,6 +503,15 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
   const long long tiles = (a.count + a.tile - 1) / a.tile;
   dim3 grid((unsigned)tiles, a.C), block(256);
   const size_t lds_bytes = sizeof(double) * (size_t(a.win) + (order == 0 && a.tab_lds ? size_t(a.L) * a.n : 0));
+  if (order >= 1 && a.coop) {
+    switch (order) {
+      case 1: hipLaunchKernelGGL(poly_coop_kernel<1>, grid, block, lds_bytes, st, in, out, a); break;
+      case 2: hipLaunchKernelGGL(poly_coop_kernel<2>, grid, block, lds_bytes, st, in, out, a); break;
+      case 3: hipLaunchKernelGGL(poly_coop_kernel<3>, grid, block, lds_bytes, st, in, out, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (order) {
     case 0: hipLaunchKernelGGL(poly_kernel<0>, grid, block, lds_bytes, st, in, out, a); break;
     case 1: hipLaunchKernelGGL(poly_kernel<1>, grid, block, lds_bytes, st, in, out, a); break;

@@ -131,6 +131,7 @@ struct PolyArgs {
   long long count;       // outputs to produce
   int C, n, L, phase_bits, tile, win;
   int tab_lds;           // order 0: copy the [L][n] table into LDS behind the window (it fits)
+  int coop;              // orders 1-3: 8 lanes per output (poly_coop_kernel); needs n % 8 == 0
 };
 
 struct HalfArgs {
