@@ -599,8 +599,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
         a.tw_fwd = twiddles(log2p);
         a.tw_inv = twiddles(log2nd);
-        a.tw_fwd8 = (log2p >= 6 && log2p <= 12) ? twiddles8(log2p) : nullptr;
-        if (log2p >= 6 && log2p <= 12 && !a.tw_fwd8) return kNoMem;
+        a.tw_fwd8 = (log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
+        if (log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
         a.tw_inv8 = (log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
         if (log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
         a.B0 = B0;

@@ -344,14 +344,16 @@ template <int LOG2M, int DIR>
 __device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M);
-  static_assert(NP >= 2 && NP <= 4, "fft8_regs: 64 <= M <= 4096");
+  static_assert(NP >= 2 && NP <= 5, "fft8_regs: 64 <= M <= 8192");
   fft8_pass<LOG2M, 8, 1, DIR, false>(u, tid, tw, lds, active);
   if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true>(u, tid, tw, lds, active);
   if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false>(u, tid, tw, lds, active);
   if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true>(u, tid, tw + 7 * 8, lds, active);
-  if constexpr (NP == 4) {
-    fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds, active);
-    fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
+  if constexpr (NP >= 4) fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds, active);
+  if constexpr (NP == 4) fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
+  if constexpr (NP == 5) {
+    fft8_pass<LOG2M, 8, 512, DIR, false>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
+    fft8_pass<LOG2M, RL, 4096, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64 + 7 * 512, lds, active);
   }
 }
 template <int LOG2M, int DIR>

@@ -66,7 +66,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   // Zp[tid + s*2*TF], and the inverse transform's thread t needs Zp[(t mod T) + T*j], j < 4: its own even slots for
   // t < 2*TF, the odd slots of thread t - 2*TF otherwise
   // (with x2 upsampling the same plan uses ALL threads, and a thread ends up with exactly the 8 values it needs)
-  constexpr bool F8 = !SPLIT && (LOG2N - LOG2P == 2 || LOG2N - LOG2P == 1) && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 12;
+  constexpr bool F8 = XMODE != 1 && (LOG2N - LOG2P == 2 || LOG2N - LOG2P == 1) && LOG2ND == LOG2N && LOG2P >= 6 && LOG2P <= 13;
   constexpr int T8 = P / 8; // threads of the 8-points-per-thread forward transform
   // Frequency-domain decimation by 2 (same block length in, half out): the kept bins k' = t + s'*T (s' < 8) of thread t
   // are its own slots 0-3 and 12-15 of the N-point spectrum, so no exchange is needed, and the ND-point inverse
@@ -474,7 +474,7 @@ template <int LOG2N, int LOG2P, int LOG2ND>
 static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  constexpr size_t lds_fwd8 = (LOG2N < 14 && LOG2ND == LOG2N && LOG2P < LOG2N && LOG2P >= 6 && LOG2P <= 12) ? 8 * size_t(fft8_lds_doubles(LOG2P)) : 0;
+  constexpr size_t lds_fwd8 = (LOG2ND == LOG2N && LOG2P < LOG2N && LOG2P >= 6 && LOG2P <= 13) ? 8 * size_t(fft8_lds_doubles(LOG2P)) : 0;
   constexpr size_t lds_bytes = std::max(lds_fwd8, LOG2N >= 14 ? 8 * size_t(N)
                                : (LOG2N == 13 && LOG2ND == 13)
                                    ? std::max(8 * size_t(fft_lds_doubles_halves(13)), LOG2P < LOG2N ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
