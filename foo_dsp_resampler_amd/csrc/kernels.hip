@@ -40,7 +40,7 @@ template <bool SPLIT> struct LdsCx {
 };
 
 template <int LOG2N, int LOG2P, int LOG2ND>
-__global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 4 : 1) void dft_kernel(AnyView in, AnyView out, DftArgs a)
+__global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 4 : (LOG2N == 12 && LOG2ND >= 11) ? 3 : 1) void dft_kernel(AnyView in, AnyView out, DftArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P, ND = 1 << LOG2ND;
   constexpr int T = N / 16, TF = P / 16, TD = ND / 16;
@@ -49,7 +49,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   // workgroups share a CU
   // 16384-point blocks that keep their length: half rounds of 16-byte elements instead of real / imaginary rounds
   // of 8-byte ones (same 128 KB, ds_*_b128 moves 1 KB in 8.4 cycles where ds_*_b64 needs 12: +7 % on the 44.1k->192k chain)
-  constexpr int XMODE = (LOG2N == 14 && LOG2ND == 14) ? 2 : SPLIT ? 1 : (LOG2N == 13 && LOG2ND == 13) ? 2 : 0;
+  // 4096-point blocks (kept length, or halved in the frequency domain): half rounds as well, so that three workgroups
+  // fit a CU instead of two
+  constexpr int XMODE = (LOG2N == 14 && LOG2ND == 14) ? 2 : SPLIT ? 1 : (LOG2N == 13 && LOG2ND == 13) ? 2 : (LOG2N == 12 && LOG2ND >= 11) ? 2 : 0;
   constexpr int ROUNDS = SPLIT ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -475,7 +477,10 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
 {
   constexpr int N = 1 << LOG2N;
   constexpr size_t lds_fwd8 = (LOG2ND == LOG2N && LOG2P < LOG2N && LOG2P >= 6 && LOG2P <= 13) ? 8 * size_t(fft8_lds_doubles(LOG2P)) : 0;
-  constexpr size_t lds_bytes = std::max(lds_fwd8, LOG2N >= 14 ? 8 * size_t(N)
+  constexpr size_t lds_d8 = (LOG2P == LOG2N && LOG2ND == LOG2N - 1 && LOG2ND >= 6 && LOG2ND <= 12) ? 8 * size_t(fft8_lds_doubles(LOG2ND)) : 0;
+  constexpr size_t lds_bytes = std::max(std::max(lds_fwd8, lds_d8), LOG2N >= 14 ? 8 * size_t(N)
+                               : (LOG2N == 12 && LOG2ND >= 11)
+                                   ? std::max(8 * size_t(fft_lds_doubles_halves(12)), (LOG2P < LOG2N && LOG2P > 13) ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
                                : (LOG2N == 13 && LOG2ND == 13)
                                    ? std::max(8 * size_t(fft_lds_doubles_halves(13)), LOG2P < LOG2N ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
                                    : 8 * size_t(fft_lds_doubles(LOG2N)));
