@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: 44.1 kHz -> 96 kHz, float32 I/O, quality Best (BASELINE.json configs[1]).
+"""bench.py -- the reference's headline workloads on the HIP engine (BASELINE.json `configs`).
 
-One "step" = one pass of the hot path over one batch of synthetic input: every rank pushes P frames of
-S independent stereo streams (already resident in HBM) through RRX_flow_device and gets the resampled
-frames written to an HBM output buffer.  Streams are independent, so N GPUs = N shards of streams with no
-data-path collective (weak scaling); torch.distributed (RCCL) is used only for the barrier and the
-max-over-ranks of the elapsed time.
+`--config K` selects BASELINE.json configs[K]; the default, 1, is the configuration the metric is quoted on
+(44.1 kHz -> 96 kHz, 2 ch float32, quality Best), so the driver's line is that one:
 
-Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job input channel-samples
-per second (Msamples/s); roofline = algorithmic HBM bytes (4*(1+out/in) = 12.707 B per input
-channel-sample) / measured step time on the launch stream, against the 8 TB/s HBM3E peak; cpu_baseline = the
-plain-C oracle ("port") timed on this box's host cores on a bounded sample of the same workload.
+  0  44.1k -> 48k   2 ch  (the reference's own CPU-runnable case; here the same chain on the GPU, 256 streams)
+  1  44.1k -> 96k   2 ch, 256 independent streams per GPU                       <- headline metric
+  2  44.1k -> 192k  8 ch, passband 99 % (long DFT-filter stage), 32 streams per GPU
+  3  96k   -> 44.1k 32 ch, aliasing off, linear phase, 16 streams per GPU
+  4  1024 independent stereo 44.1k -> 48k streams, sharded over the ranks (`--gpus N`: 1024/N streams each)
+
+One "step" = one pass of the hot path over one batch of synthetic input: every rank pushes P frames of its S
+independent streams (already resident in HBM) through RRX_flow_device and gets the resampled frames written to an
+HBM output buffer.  Streams are independent (rate_base.h:533-540), so N GPUs = N shards of streams with no
+data-path collective; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job input channel-samples per
+second (Msamples/s); roofline = algorithmic HBM bytes (4*(1+out/in) B per input channel-sample) /
+summed HIP-event time of the chain's stage kernels on the launch stream, against the 8 TB/s HBM3E peak, with the
+kernel names reported by the engine (RRX_profile_report), the HBM traffic looked up in profiles/traffic.json (PMC
+passes; null when no pass matches this exact workload and kernel) and the fp64 issue fraction next to it;
+cpu_baseline = the plain-C oracle ("port") timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import threading
@@ -24,29 +35,64 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-IN_RATE, OUT_RATE, NCH = 44100, 96000, 2
-BYTES_PER_UNIT = 4.0 * (1.0 + OUT_RATE / IN_RATE)  # 12.707 B per input channel-sample
-HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per fused_kernel launch from the PMC passes (profiles/r01_traffic.md); None until measured
-TRAFFIC_BYTES_PER_LAUNCH = 3276.0e6  # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, one launch = one 481 689-frame push of 256 streams
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6   # MI355X vector = matrix fp64 peak (spec); tools/ubench_mfma.hip measures 77.3 for any mix
+
+# BASELINE.json configs[K] -> workload.  streams = independent streams per GPU (config 4: total over all ranks).
+CONFIGS = {
+    0: dict(name="BASELINE configs[0]: 44.1k->48k 2ch float32 Best (the reference's CPU-runnable case, on the GPU)",
+            fi=44100, fo=48000, nch=2, streams=256, kw={}),
+    1: dict(name="BASELINE configs[1]: 44.1k->96k 2ch float32 Best", fi=44100, fo=96000, nch=2, streams=256, kw={}),
+    2: dict(name="BASELINE configs[2]: 44.1k->192k 8ch float32 Best, passband 99 % (long DFT-filter stage)",
+            fi=44100, fo=192000, nch=8, streams=32, kw={"bandwidth": 99.0}),
+    3: dict(name="BASELINE configs[3]: 96k->44.1k 32ch float32 Best, aliasing off, linear phase",
+            fi=96000, fo=44100, nch=32, streams=16, kw={"allow_aliasing": 0, "phase": 50.0}),
+    4: dict(name="BASELINE configs[4]: 1024 independent stereo 44.1k->48k streams sharded over the ranks",
+            fi=44100, fo=48000, nch=2, streams=1024, kw={}, total=True, frames=240000),
+}
 
 
-def cpu_baseline(seconds_single=4.0, seconds_multi=8.0):
+def chain_flops_per_unit(plan, fi):
+    """fp64 flops per input channel-sample of the chain the planner built (what the reference's algorithm costs at
+    complex-FFT efficiency: 5 N log2 N per transform shared by a channel pair, 6 per spectrum multiply, 2 per tap)."""
+    rate, total = 1.0, 0.0   # rate = stage-input samples per chain-input sample
+    for s in plan["stages"]:
+        if s["kind"] == "dft":
+            N, L, taps = s["dft_length"], s["L"], s["num_taps"]
+            V = N - (taps - 1)
+            P = N // L if L in (1, 2, 4) else N
+            step = s["step_int"]
+            Nd = N >> (-step) if step < 0 else N
+            fl = 5.0 * P * math.log2(P) + 6.0 * N + 5.0 * Nd * math.log2(Nd)   # per block of one channel PAIR
+            consumed = V / L                                                    # stage-input samples per block and channel
+            total += rate * fl / (2.0 * consumed)
+            rate *= L / (step if step > 0 else float(1 << -step))
+        elif s["kind"] == "poly":
+            ratio = s["L"] * 4294967296.0 / s["step"]  # outputs per input: the clock advances step/2^32 of L phases per output
+            total += rate * ratio * 2.0 * s["n"] * (s["interp_order"] + 1)
+            rate *= ratio
+        else:
+            total += rate * 0.5 * (2.0 * 2 * s["n"] + 1)
+            rate *= 0.5
+    return total
+
+
+def cpu_baseline(cfg, seconds_single=4.0, seconds_multi=8.0):
     """Oracle (plain-C port of the reference path) on the host cores: 1 thread, then all threads with one
     independent handle per thread (streams are independent).  Bounded by wall time."""
-    import numpy as np
     from oracle_binding import Oracle, lcg_noise
 
     chunk = 65536
-    x = lcg_noise(chunk, NCH, 12345)
+    nch = cfg["nch"]
+    x = lcg_noise(chunk, nch, 12345)
 
     def worker(deadline, out, idx):
-        o = Oracle(IN_RATE, OUT_RATE, NCH)
+        o = Oracle(cfg["fi"], cfg["fo"], nch, **cfg["kw"])
         n = 0
         while time.perf_counter() < deadline:
             o.push(x)
             o.pull_all()
-            n += chunk * NCH
+            n += chunk * nch
         out[idx] = n
 
     res = [0]
@@ -65,8 +111,23 @@ def cpu_baseline(seconds_single=4.0, seconds_multi=8.0):
     multi = sum(res) / (time.perf_counter() - t0) / 1e6
     return {"value": round(multi, 2), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "single_thread_value": round(single, 2),
-            "sample": "oracle/rate_oracle.c, 44.1k->96k 2ch Best, 65536-frame pushes of LCG noise, one handle per "
-                      "thread, %.0f s wall on %d threads (plus %.0f s on 1 thread)" % (seconds_multi, threads, seconds_single)}
+            "sample": "oracle/rate_oracle.c, %d->%d %dch, 65536-frame pushes of LCG noise, one handle per thread, "
+                      "%.0f s wall on %d threads (plus %.0f s on 1 thread)" % (cfg["fi"], cfg["fo"], nch, seconds_multi,
+                                                                               threads, seconds_single)}
+
+
+def lookup_traffic(config, streams, frames, kernel):
+    """HBM bytes per launch of `kernel` from the tracked PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            recs = json.load(f)["records"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for r in recs:
+        if r.get("config") == config and r.get("streams_per_gpu") == streams and r.get("frames_per_push") == frames \
+                and r.get("kernel") == kernel:
+            return r.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -74,12 +135,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=256, help="independent stereo streams per GPU")
-    ap.add_argument("--frames", type=int, default=0, help="frames per push (default: isamp_max = 481689)")
-    ap.add_argument("--total-streams", type=int, default=0,
-                    help="strong partition: this many streams split over the ranks (e.g. 1024 = BASELINE configs[4] shape)")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[K] (default 1: the headline metric)")
+    ap.add_argument("--streams", type=int, default=0, help="override: independent streams per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="override: frames per push (default: isamp_max, rate_base.h:531)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    fi, fo, nch, kw = cfg["fi"], cfg["fo"], cfg["nch"], cfg["kw"]
+    bytes_per_unit = 4.0 * (1.0 + fo / fi)
 
     import torch
     import foo_dsp_resampler_amd as F
@@ -103,19 +166,22 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from foo_dsp_resampler_amd.sharding import shard_range
-    S = args.streams
-    if args.total_streams:
-        _, S = shard_range(args.total_streams, world, rank)
-    r = F.Resampler(IN_RATE, OUT_RATE, nch=NCH, nstreams=S)
-    P = args.frames or r.isamp_max
-    P = min(P, r.isamp_max)
+    strong = bool(cfg.get("total")) and not args.streams
+    if args.streams:
+        S = args.streams
+    elif strong:
+        _, S = shard_range(cfg["streams"], world, rank)  # a fixed set of streams split over the ranks
+    else:
+        S = cfg["streams"]
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    P = min(args.frames or cfg.get("frames") or r.isamp_max, r.isamp_max)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
 
     g = torch.Generator(device="cuda").manual_seed(12345 + rank)
-    x = torch.rand((S, P, NCH), generator=g, device="cuda", dtype=torch.float32) - 0.5
-    cap = int(P * OUT_RATE / IN_RATE) + 8192
-    y = torch.empty((S, cap, NCH), device="cuda", dtype=torch.float32)
+    x = torch.rand((S, P, nch), generator=g, device="cuda", dtype=torch.float32) - 0.5
+    cap = int(P * fo / fi) + 8192
+    y = torch.empty((S, cap, nch), device="cuda", dtype=torch.float32)
 
     def step():
         iu, og = r.flow_device(x, P, y, cap)
@@ -146,10 +212,10 @@ def main():
     r.profile(True)
     for _ in range(args.steps):
         step()
-    prof = r.profile_read()         # summed per-launch durations of the dominant kernel / the rest
+    kernels = r.profile_report()    # per kernel instance: launches and summed duration, names as rocprofv3 prints them
     r.profile(False)
 
-    units_per_step_rank = S * P * NCH                    # input channel-samples per step on this GPU
+    units_per_step_rank = S * P * nch                    # input channel-samples per step on this GPU
     units_all = units_per_step_rank
     if dist:
         rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -162,37 +228,58 @@ def main():
     total_units = units_all * args.steps
     value = total_units / elapsed / 1e6
     step_dev_s = dev_ms / 1e3 / args.steps
-    # dominant kernel = rsmp::fused_kernel (FFT-FIR + polyphase of one block per workgroup); every launch
-    # of a step together covers the step's units, so bytes/launch / avg launch time = step bytes / summed time
-    hot_s = prof["hot_ms"] / 1e3 / args.steps
-    achieved_gbs = units_per_step_rank * BYTES_PER_UNIT / hot_s / 1e9
 
     if rank == 0:
+        plan = F.describe_plan(fi, fo, **kw)
+        # dominant kernel = the instance with the largest summed time; the chain's stage kernels (hot) together cover
+        # a step's units, so bytes per launch / average launch time = step bytes / summed time per step
+        kernels.sort(key=lambda k: -k["ms"])
+        dom = kernels[0] if kernels else {"kernel": None, "launches": 0, "ms": 0.0}
+        chain = [k for k in kernels if k["kernel"] not in ("rsmp::fused_prep_kernel",)]
+        chain_ms = sum(k["ms"] for k in chain) / args.steps
+        dom_ms_per_step = dom["ms"] / args.steps
+        launches_per_step = dom["launches"] / args.steps if dom["launches"] else 0
+        alg_bytes_step = units_per_step_rank * bytes_per_unit
+        # roofline of the dominant kernel: in a fused chain it carries all of the step's algorithmic bytes; in a
+        # modular chain the bytes belong to the whole sequence of stage kernels, so the chain time is the divisor
+        fused = dom["kernel"] is not None and "fused_kernel" in dom["kernel"]
+        div_ms = dom_ms_per_step if fused else chain_ms
+        achieved_gbs = alg_bytes_step / (div_ms / 1e3) / 1e9 if div_ms else 0.0
+        flops_unit = chain_flops_per_unit(plan, fi)
         out = {
-            "metric": "Msamples/s, 44.1k->96k float32 'Best' (input channel-samples)",
+            "metric": "Msamples/s, %s float32 'Best' (input channel-samples)" % ("%.4gk->%.4gk" % (fi / 1e3, fo / 1e3)),
             "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if args.total_streams else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 44.1k->96k 2ch float32 Best; %d independent stereo streams "
-                                   "per GPU, %d frames per push, device-resident in/out (RRX_flow_device)" % (S, P),
-                       "streams_per_gpu": S, "frames_per_push": P, "channels": NCH,
-                       "output_Msamples_per_s": round(value * OUT_RATE / IN_RATE, 2),
+            "config": {"workload": "%s; %d independent %d-channel streams on this GPU%s, %d frames per push, device-resident "
+                                   "in/out (RRX_flow_device)" % (cfg["name"], S, nch, " (of %d over %d ranks)" % (cfg["streams"], world) if strong else "", P),
+                       "baseline_config_index": args.config,
+                       "streams_per_gpu": S, "frames_per_push": P, "channels": nch,
+                       "chain": "->".join("%s" % s["kind"] for s in plan["stages"]),
+                       "output_Msamples_per_s": round(value * fo / fi, 2),
                        "out_frames_per_stream": out_frames},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                         "kernel": "rsmp::fused_kernel<12,11,2,7,true> (dft L2 N4096 -> vpoly0 160/147 on v_mfma_f64_4x4x4 -> float32)",
-                         "launches_per_step": prof["hot_launches"] / args.steps,
-                         "avg_launch_ms": round(prof["hot_ms"] / max(1, prof["hot_launches"]), 5),
-                         "algorithmic_bytes_per_launch": round(units_per_step_rank * BYTES_PER_UNIT * args.steps
-                                                               / max(1, prof["hot_launches"])),
-                         "other_kernels_ms_per_step": round(prof["other_ms"] / args.steps, 5),
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
+                         "traffic": lookup_traffic(args.config, S, P, dom["kernel"]),
+                         "kernel": dom["kernel"],
+                         "kernel_time_basis": "dominant kernel (fused chain)" if fused else "sum of the chain's stage kernels",
+                         "launches_per_step": launches_per_step,
+                         "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5),
+                         "algorithmic_bytes_per_launch": round(alg_bytes_step / max(1.0, launches_per_step)) if fused else None,
+                         "algorithmic_bytes_per_step": round(alg_bytes_step),
+                         "bytes_per_unit": round(bytes_per_unit, 4),
+                         "kernels_ms_per_step": {k["kernel"]: round(k["ms"] / args.steps, 5) for k in kernels},
                          "device_ms_per_step": round(step_dev_s * 1e3, 4),
-                         "whole_step_frac": round(units_per_step_rank * BYTES_PER_UNIT / step_dev_s / 1e9 / HBM_PEAK_GBS, 5)},
+                         "whole_step_frac": round(alg_bytes_step / step_dev_s / 1e9 / HBM_PEAK_GBS, 5),
+                         # fp64 work of the chain at complex-FFT efficiency / the vector(=matrix) fp64 peak
+                         "fp64_flops_per_unit": round(flops_unit, 1),
+                         "fp64_issue_frac": round(units_per_step_rank * flops_unit / (div_ms / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 5) if div_ms else None,
+                         "fp64_peak_tflops": FP64_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -3,8 +3,6 @@
 #include "../../include/ratelib_amd.h"
 
 #include "engine.hpp"
-#include "plugin_host.hpp"
-#include "lpc.hpp"
 
 #include <cstring>
 #include <new>
@@ -91,6 +89,7 @@ int init_ratelib(void (*alloc_error_handler)(void))
   g_alloc_handler = alloc_error_handler;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return -1; // no GPU: refuse loudly, there is no CPU path
+  if (!rsmp::device_is_gfx950()) return -1;                    // the code object is gfx950-only: refuse here, not at the first launch
   g_initialized = 1;
   return 0;
 }
@@ -185,8 +184,7 @@ int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t 
 int RRX_set_stream(RR_handle *h, void *hip_stream)
 {
   if (!h) return RR_NULLHANDLE;
-  h->eng->set_stream(static_cast<hipStream_t>(hip_stream));
-  return RR_OK;
+  return guarded([&] { return h->eng->set_stream(static_cast<hipStream_t>(hip_stream)); });
 }
 
 int RRX_sync(RR_handle *h)
@@ -207,6 +205,21 @@ int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, doub
   if (!h) return RR_NULLHANDLE;
   return guarded([&] { return h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches); });
 }
+
+int RRX_profile_report(RR_handle *h, char *buf, size_t cap)
+{
+  if (!h) return -RR_NULLHANDLE;
+  if (!buf || !cap) return -RR_INVPARAM;
+  std::string s;
+  int rc = guarded([&] { return h->eng->read_profile_json(s); });
+  if (rc) return -rc;
+  size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+  std::memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  return int(n);
+}
+
+void RRX_debug_fail_alloc(int nth) { rsmp::Engine::fail_alloc_after(nth); }
 
 size_t RRX_isamp_max(const RR_handle *h) { return h ? h->eng->isamp_max() : 0; }
 size_t RRX_available(const RR_handle *h) { return h ? h->eng->available() : 0; }
@@ -237,110 +250,6 @@ int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, 
   if (out)
     for (size_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
   return RR_OK;
-}
-
-// ---- plugin layer ----------------------------------------------------------------------------------
-} // extern "C"
-
-struct DSPR_handle_tag {
-  rsmp::DspRate *dsp;
-  std::deque<rsmp::AudioChunk> out;
-};
-
-extern "C" {
-
-int DSPR_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase, DSPR_handle **h)
-{
-  if (!h) return RR_INVPARAM;
-  *h = nullptr;
-  if (!g_initialized) return RR_EXTUNINIT;
-  rsmp::RateSettings s;
-  s.out_rate = out_rate;
-  s.quality = quality;
-  s.allow_aliasing = allow_aliasing;
-  s.passband10 = passband10;
-  s.phase = phase;
-  DSPR_handle *d = new (std::nothrow) DSPR_handle_tag();
-  if (!d) return finish(RR_ENOMEM);
-  d->dsp = new (std::nothrow) rsmp::DspRate(s);
-  if (!d->dsp) {
-    delete d;
-    return finish(RR_ENOMEM);
-  }
-  *h = d;
-  return RR_OK;
-}
-
-void DSPR_destroy(DSPR_handle **h)
-{
-  if (!h || !*h) return;
-  delete (*h)->dsp;
-  delete *h;
-  *h = nullptr;
-}
-
-int DSPR_on_chunk(DSPR_handle *h, const fb_sample_t *data, size_t frames, unsigned channels, unsigned sample_rate,
-                  unsigned channel_config, int *passthrough)
-{
-  if (!h) return RR_NULLHANDLE;
-  return guarded([&] {
-    rsmp::AudioChunk c;
-    c.data.assign(data, data + frames * channels);
-    c.frames = frames;
-    c.channels = channels;
-    c.sample_rate = sample_rate;
-    c.channel_config = channel_config;
-    const bool pass = h->dsp->on_chunk(c, h->out);
-    if (passthrough) *passthrough = pass ? 1 : 0;
-    return h->dsp->last_error();
-  });
-}
-
-int DSPR_end_of_track(DSPR_handle *h)
-{
-  if (!h) return RR_NULLHANDLE;
-  return guarded([&] {
-    h->dsp->on_endoftrack(h->out);
-    return h->dsp->last_error();
-  });
-}
-
-void DSPR_flush(DSPR_handle *h)
-{
-  if (h) h->dsp->flush();
-}
-
-double DSPR_get_latency(const DSPR_handle *h) { return h ? h->dsp->get_latency() : 0.0; }
-
-int DSPR_peek_output(const DSPR_handle *h, size_t *frames, unsigned *channels, unsigned *sample_rate)
-{
-  if (!h) return RR_NULLHANDLE;
-  if (h->out.empty()) {
-    if (frames) *frames = 0;
-    return RR_OK;
-  }
-  const rsmp::AudioChunk &c = h->out.front();
-  if (frames) *frames = c.frames;
-  if (channels) *channels = c.channels;
-  if (sample_rate) *sample_rate = c.sample_rate;
-  return RR_OK;
-}
-
-int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames)
-{
-  if (!h) return RR_NULLHANDLE;
-  if (h->out.empty()) return RR_INVPARAM;
-  const rsmp::AudioChunk &c = h->out.front();
-  if (!dst || cap_frames < c.frames) return RR_INVPARAM;
-  std::memcpy(dst, c.data.data(), c.frames * c.channels * sizeof(float));
-  h->out.pop_front();
-  return RR_OK;
-}
-
-void DSPR_lpc_extrapolate(fb_sample_t *data, size_t data_len, int nch, int lpc_order, size_t extra_bkwd, size_t extra_fwd)
-{
-  if (!data || nch <= 0 || lpc_order <= 0) return;
-  guarded([&] { rsmp::lpc_extrapolate(data, data_len, nch, lpc_order, extra_bkwd, extra_fwd); return 0; });
 }
 
 } // extern "C"

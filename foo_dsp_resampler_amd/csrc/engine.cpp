@@ -5,6 +5,8 @@
 #include "design.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +17,11 @@ namespace rsmp {
 namespace {
 
 bool pow2_ge2(int x) { return x >= 2 && !(x & (x - 1)); }
+// x2 / x4 upsampling runs in the frequency domain (forward transform of N/L points, spectrum replicated: dft_filter.h:86-104).
+// Larger powers of two (x32 and beyond as a whole: e.g. 8000 -> 352800) take the kernels' time-domain zero-stuffing
+// branch instead: the reference's replication IS the spectrum of the block zero-stuffed from slot 0, so the two agree
+// to fp64 rounding; the reference's counters (remL untouched on this branch) are mirrored as they are.
+bool fdomain_up(int L) { return pow2_ge2(L) && L <= 4; }
 int ilog2(long long v) { int l = 0; while ((1LL << l) < v) ++l; return l; }
 long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; return p; }
 
@@ -25,6 +32,19 @@ long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; retur
   } while (0)
 
 // host mirror of fft_device.hpp's schedule
+} // namespace
+
+// true when the current device can run this library's code object (built with --offload-arch=gfx950 only)
+bool device_is_gfx950()
+{
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+namespace {
+
 int first_radix(int log2m) { return (log2m & 3) ? (1 << (log2m & 3)) : 16; }
 int num_passes(int log2m) { return (log2m + 3) / 4; }
 
@@ -35,6 +55,7 @@ int Engine::create(const Config &cfg, int nch, int nstreams, Engine **out)
   if (!out) return kInvParam;
   *out = nullptr;
   if (nch < 1 || nstreams < 1) return kInvParam;
+  if ((long long)nch * nstreams > INT_MAX / 4096) return kNoMem; // more channels than any device could hold fifos for
   Engine *e = new (std::nothrow) Engine();
   if (!e) return kNoMem;
   int rc = e->init(cfg, nch, nstreams);
@@ -46,9 +67,31 @@ int Engine::create(const Config &cfg, int nch, int nstreams, Engine **out)
   return kOk;
 }
 
+namespace { std::atomic<int> g_fail_alloc{0}; }
+
+void Engine::fail_alloc_after(int n) { g_fail_alloc.store(n > 0 ? n : 0); }
+
+// every device allocation of the engine goes through here (RR_ENOMEM mapping, test failpoint)
+int Engine::dev_alloc(void **p, size_t bytes)
+{
+  *p = nullptr;
+  if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1) == 1) return kNoMem;
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return kOk;
+  (void)hipGetLastError(); // the failure is reported through the return code; do not leave it sticky
+  *p = nullptr;
+  return e == hipErrorOutOfMemory ? kNoMem : kInternal;
+}
+
+#define ALLOC_TRY(ptr, bytes)                                             \
+  do {                                                                    \
+    int rc_ = dev_alloc(reinterpret_cast<void **>(ptr), (bytes));         \
+    if (rc_ != kOk) return rc_;                                           \
+  } while (0)
+
 int Engine::upload(const void *src, size_t bytes, void **dst)
 {
-  HIP_TRY(hipMalloc(dst, bytes));
+  ALLOC_TRY(dst, bytes);
   HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   return kOk;
 }
@@ -104,8 +147,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
 
   int dev_count = 0;
   if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1) return kUninit; // no HIP device: fail loudly
-  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  own_stream_ = true;
+  if (!device_is_gfx950()) return kUninit; // the code object is built for gfx950 only: refuse here, not at the first launch
+  HIP_TRY(hipStreamCreateWithFlags(&own_, hipStreamNonBlocking));
+  stream_ = own_;
+  HIP_TRY(hipEventCreateWithFlags(&ev_switch_, hipEventDisableTiming));
   HIP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&ev_fused_, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_seam_[0], hipEventDisableTiming));
@@ -114,7 +159,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   dbg_ = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
   no_side_ = getenv("RSMP_NO_SIDE") != nullptr;
   if (getenv("RSMP_STAMPS")) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stamps_), 8 * sizeof(unsigned long long)));
+    ALLOC_TRY(&stamps_, 8 * sizeof(unsigned long long));
     HIP_TRY(hipMemset(stamps_, 0, 8 * sizeof(unsigned long long)));
   }
   const int ns = int(plan_.stages.size());
@@ -145,7 +190,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       }
       const int Ng = dg.Ng;
       const int log2n = ilog2(Ng);
-      const int log2p = pow2_ge2(sp.L) ? log2n - ilog2(sp.L) : log2n;
+      const int log2p = fdomain_up(sp.L) ? log2n - ilog2(sp.L) : log2n;
       const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
       if (!dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
       st.remL = sp.remL0;
@@ -206,9 +251,9 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     fu.blk_cap = 64;
     while (fu.blk_cap < kFusedMaxBlocks && size_t(C_ + 1) * size_t(4 * fu.blk_cap) * 512 <= (size_t(320) << 20)) fu.blk_cap *= 2;
     fu.slots = 2 * fu.blk_cap;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.blk_dev), size_t(fu.blk_cap) * sizeof(FusedBlock)));
+    ALLOC_TRY(&fu.blk_dev, size_t(fu.blk_cap) * sizeof(FusedBlock));
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&fu.seam), bytes));
+    ALLOC_TRY(&fu.seam, bytes);
     HIP_TRY(hipMemset(fu.seam, 0, bytes));
     const int V = f.N - (f.num_taps - 1);
     // periods a block can touch: ceil(outputs per block / L) + 1; chunk length fixed from it
@@ -313,7 +358,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     pm.NGRP = NGRP;
     pm.Vt = Vt;
     pm.blk_cap = 4096;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pm.blk), size_t(pm.blk_cap) * sizeof(FusedBlock)));
+    ALLOC_TRY(&pm.blk, size_t(pm.blk_cap) * sizeof(FusedBlock));
   }
   // the fifo between two fused stages carries no bulk data
   bytes_per_in_frame = 0;
@@ -349,11 +394,12 @@ void Engine::set_profiling(bool on)
   prof_.clear();
 }
 
-int Engine::prof_begin(bool hot)
+int Engine::prof_begin(bool hot, const char *name)
 {
   if (!profiling_) return -1;
   ProfRec r;
   r.hot = hot;
+  r.name = name;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
   (void)hipEventRecord(r.e0, stream_);
   prof_.push_back(r);
@@ -388,6 +434,41 @@ int Engine::read_profile(double *hot_ms, long long *hot_launches, double *other_
   return kOk;
 }
 
+int Engine::read_profile_json(std::string &out)
+{
+  HIP_TRY(hipStreamSynchronize(stream_));
+  struct Agg { const char *name; bool hot; long long n; double ms; };
+  std::vector<Agg> agg;
+  for (ProfRec &r : prof_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      Agg *a = nullptr;
+      for (Agg &x : agg)
+        if (std::strcmp(x.name, r.name) == 0 && x.hot == r.hot) a = &x;
+      if (!a) {
+        agg.push_back(Agg{r.name, r.hot, 0, 0.0});
+        a = &agg.back();
+      }
+      a->n += 1;
+      a->ms += ms;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  prof_.clear();
+  out = "[";
+  char buf[64];
+  for (size_t i = 0; i < agg.size(); ++i) {
+    out += i ? ", {" : "{";
+    out += "\"kernel\": \"";
+    out += agg[i].name;
+    snprintf(buf, sizeof buf, "\", \"hot\": %d, \"launches\": %lld, \"ms\": %.6f}", agg[i].hot ? 1 : 0, agg[i].n, agg[i].ms);
+    out += buf;
+  }
+  out += "]";
+  return kOk;
+}
+
 // make the main stream wait for the seam kernels still running on the side stream
 int Engine::join_side()
 {
@@ -406,6 +487,7 @@ void Engine::free_garbage()
 Engine::~Engine()
 {
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (own_ && own_ != stream_) (void)hipStreamSynchronize(own_);
   free_garbage();
   for (Ring &r : rings_) if (r.buf) (void)hipFree(r.buf);
   for (double2 *&g : d_G_) if (g) (void)hipFree(g);
@@ -435,7 +517,19 @@ Engine::~Engine()
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
   if (ev_fused_) (void)hipEventDestroy(ev_fused_);
   for (hipEvent_t &e : ev_seam_) if (e) (void)hipEventDestroy(e);
-  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  if (ev_switch_) (void)hipEventDestroy(ev_switch_);
+  if (own_) (void)hipStreamDestroy(own_); // never the caller's stream
+}
+
+int Engine::set_stream(hipStream_t s)
+{
+  hipStream_t next = s ? s : own_;
+  if (next == stream_) return kOk;
+  { int rcj = join_side(); if (rcj) return rcj; } // seam kernels still on the side stream belong to the old stream's work
+  HIP_TRY(hipEventRecord(ev_switch_, stream_));
+  HIP_TRY(hipStreamWaitEvent(next, ev_switch_, 0));
+  stream_ = next;
+  return kOk;
 }
 
 int Engine::sync()
@@ -491,7 +585,7 @@ int Engine::ensure_ring(int f, long long live_needed)
   const long long cap = next_pow2(std::max<long long>({live_needed, r.cap * 2, 4096}));
   const size_t bytes = r.f32 ? size_t(cap) * nch_ * S_ * sizeof(float) : size_t(cap) * C_ * sizeof(double);
   void *nb = nullptr;
-  HIP_TRY(hipMalloc(&nb, bytes));
+  ALLOC_TRY(&nb, bytes);
   HIP_TRY(hipMemsetAsync(nb, 0, bytes, stream_));
   if (r.buf) {
     Ring old = r;
@@ -595,7 +689,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         const int log2n = ilog2(Ng);
         DftArgs a;
         a.G = d_G_[sp.filt];
-        const int log2p = pow2_ge2(L) ? log2n - ilog2(L) : log2n;
+        const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
         const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
         a.tw_fwd = twiddles(log2p);
         a.tw_inv = twiddles(log2nd);
@@ -608,7 +702,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.nblocks = nblocks;
         a.C = C_;
         a.L = L;
-        a.c0 = sp.remL0;
+        a.c0 = pow2_ge2(L) ? 0 : sp.remL0; // the frequency-domain branch places input 0 of a block at slot 0 whatever remL is
         a.V = Vg;
         a.Vout = sp.step < 0 ? Ng - ((((1 << -sp.step) - 1) * Ng + ov) >> -sp.step) : Vg;
         a.q = (Vg - sp.remL0 + L - 1) / L;
@@ -636,9 +730,11 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pend_log2p = log2p;
         } else {
         const int pi = prof_begin(true);
+        const char *kn = nullptr;
         HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                            src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                           dst_f32 ? nod : f64_view(i + 1), a, stream_));
+                           dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+        prof_name(pi, kn);
         prof_end(pi);
         }
       }
@@ -694,7 +790,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.clip_hi = 0x7fffffffffffffffLL;
           for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
             if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
-          HIP_TRY(launch_fused_prep(pa, fu.blk_dev, stream_));
+          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, fu.blk_dev, stream_)); prof_end(pp); }
           fa.blk = fu.blk_dev;
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
@@ -703,13 +799,15 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           if (seam_launches_ >= 2) // seam(k-2) read the slots this launch overwrites
             HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
           const int pi = prof_begin(true);
+          const char *kn = nullptr;
           HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
                                s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                               dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+                               dst_f32 ? nod : f64_view(i + 1), fa, stream_, &kn));
+          prof_name(pi, kn);
           prof_end(pi);
           // side stream only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
           if (profiling_ || !dst_f32 || no_side_) {
-            const int ps = prof_begin(false);
+            const int ps = prof_begin(false, "rsmp::seam_kernel");
             HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
             prof_end(ps);
           } else {
@@ -744,7 +842,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.clip_hi = i_end;
           for (int k : {0, pa.nblocks - 1})
             if (fused_block_info(pa, k).K > 32) return kInternal; // 4 column steps x 2 halves x 4 periods
-          HIP_TRY(launch_fused_prep(pa, pm.blk, stream_));
+          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, pm.blk, stream_)); prof_end(pp); }
           PolyMfArgs a;
           a.cfm = pm.cfm;
           a.blk = pm.blk;
@@ -760,8 +858,10 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           a.step = int(step);
           a.NGRP = pm.NGRP;
           const int pi = prof_begin(false);
+          const char *kn = nullptr;
           HIP_TRY(launch_polymf(pm.KS, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                                dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_));
+                                dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+          prof_name(pi, kn);
           prof_end(pi);
         }
       } else if (launch && count) {
@@ -794,9 +894,11 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.tab_lds = tab_lds;
         a.coop = sp.order >= 1 && sp.n % 8 == 0 && !getenv("RSMP_NO_POLYCOOP");
         const int pi = prof_begin(false);
+        const char *kn = nullptr;
         HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
                             src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                            dst_f32 ? nod : f64_view(i + 1), a, stream_));
+                            dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+        prof_name(pi, kn);
         prof_end(pi);
       }
       if (sp.order == 0) {
@@ -821,8 +923,12 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.ncoef = sp.hb_n;
         a.pre = sp.pre;
         for (int k = 0; k < 13; ++k) a.coef[k] = k < sp.hb_n ? sp.hb[k] : 0.0;
+        const int pi = prof_begin(false);
+        const char *kn = nullptr;
         HIP_TRY(launch_half(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                            dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_));
+                            dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+        prof_name(pi, kn);
+        prof_end(pi);
       }
       if (2 * num_out <= occ) rd += 2 * num_out; // fifo_read refuses to over-read, fifo.h:169
       wro += num_out;
@@ -836,6 +942,14 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
 // out_cap produced frames are written straight into d_out (and counted as pulled).
 int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
                  size_t *direct_out)
+{
+  if (poisoned_) return kInternal;
+  // from here on the counters move together with the launches: any failure leaves them skewed -> poison the handle
+  return fail(feed_impl(d_in, stride_frames, isamp, d_out, out_stride, out_cap, direct_out));
+}
+
+int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
+                      size_t *direct_out)
 {
   if (direct_out) *direct_out = 0;
   ExtIn ein;
@@ -880,6 +994,7 @@ int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d
 
 int Engine::push_device(const float *ibuf, size_t stream_stride, size_t isamp)
 {
+  if (poisoned_) return kInternal;
   if (!ibuf || !isamp) return kOk; // rate_base.h:623
   if (isamp > plan_.isamp_max) isamp = plan_.isamp_max; // silently truncated, rate_base.h:624
   return feed(ibuf, S_ > 1 ? stream_stride : isamp, isamp, nullptr, 0, 0, nullptr);
@@ -887,6 +1002,7 @@ int Engine::push_device(const float *ibuf, size_t stream_stride, size_t isamp)
 
 int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
 {
+  if (poisoned_) return kInternal;
   if (!ibuf || !isamp) return kOk;
   if (isamp > plan_.isamp_max) isamp = plan_.isamp_max;
   const size_t need = isamp * size_t(nch_) * size_t(S_);
@@ -895,7 +1011,7 @@ int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
     if (d_stage_) (void)hipFree(d_stage_);
     d_stage_ = nullptr;
     stage_floats_ = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_stage_), need * sizeof(float)));
+    ALLOC_TRY(&d_stage_, need * sizeof(float));
     stage_floats_ = need;
   }
   const size_t row = isamp * nch_ * sizeof(float);
@@ -922,6 +1038,7 @@ int Engine::copy_out(float *dst, size_t stride_frames, size_t frames, bool to_ho
       done += n;
     }
     HIP_TRY(hipStreamSynchronize(stream_));
+    free_garbage(); // everything queued before this point has finished: retired rings / drain buffers can go
   } else {
     ExtOut eo;
     eo.ptr = dst;
@@ -937,6 +1054,10 @@ int Engine::copy_out(float *dst, size_t stride_frames, size_t frames, bool to_ho
 
 int Engine::pull_host(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen)
 {
+  if (poisoned_) {
+    if (ogen) *ogen = 0;
+    return kInternal;
+  }
   if (!obuf || !osamp) { // rate_base.h:647
     if (ogen) *ogen = 0;
     return kOk;
@@ -954,6 +1075,10 @@ int Engine::pull_host(float *obuf, size_t stream_stride, size_t osamp, size_t *o
 
 int Engine::pull_device(float *obuf, size_t stream_stride, size_t osamp, size_t *ogen)
 {
+  if (poisoned_) {
+    if (ogen) *ogen = 0;
+    return kInternal;
+  }
   if (!obuf || !osamp) {
     if (ogen) *ogen = 0;
     return kOk;
@@ -1013,6 +1138,7 @@ int Engine::flow_device(const float *ibuf, size_t in_stride, float *obuf, size_t
 // rate_base.h:454-468,662-672
 int Engine::drain()
 {
+  if (poisoned_) return kInternal;
   const size_t target = size_t(double(book_.samples_in) / plan_.factor + .5);
   if (target <= book_.samples_out) return kOk;
   const size_t remaining = target - book_.samples_out;
@@ -1024,17 +1150,17 @@ int Engine::drain()
   while (size_t(trial.wr.back() - trial.rd.back()) < remaining) {
     int rc = advance(trial, 1024, false, no_in, no_out);
     if (rc) return rc;
-    if (++blocks > (1u << 20)) return kInternal;
+    if (++blocks > (1u << 20)) return fail(kInternal);
   }
   if (blocks) {
     const size_t frames = blocks * 1024, floats = frames * size_t(nch_) * size_t(S_);
     float *zeros = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&zeros), floats * sizeof(float)));
+    ALLOC_TRY(&zeros, floats * sizeof(float));
     HIP_TRY(hipMemsetAsync(zeros, 0, floats * sizeof(float), stream_));
     // feed them one reference block at a time so that the counter wrap in rate_input sees the same sequence
     for (size_t k = 0; k < blocks; ++k) {
       int rc = feed(zeros + k * 1024 * nch_, frames, 1024, nullptr, 0, 0, nullptr);
-      if (rc) { garbage_.push_back(zeros); return rc; }
+      if (rc) { garbage_.push_back(zeros); return fail(rc); }
     }
     garbage_.push_back(zeros);
   }

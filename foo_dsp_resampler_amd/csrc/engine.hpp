@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace rsmp {
@@ -40,9 +41,13 @@ public:
   size_t isamp_max() const { return plan_.isamp_max; }
   size_t available() const { return size_t(book_.wr.back() - book_.rd.back()); }
 
-  void set_stream(hipStream_t s) { stream_ = s; }
+  // Use the caller's stream for everything from now on (nullptr: back to the handle's own stream).  Work already
+  // queued on the previous stream is ordered before anything queued later (event on the old stream, wait on the new).
+  int set_stream(hipStream_t s);
   hipStream_t stream() const { return stream_; }
   int sync();
+  // test hook: make the n-th device allocation from now on (n >= 1, process-wide) fail with hipErrorOutOfMemory; 0 disarms
+  static void fail_alloc_after(int n);
 
   // Host-memory API (RR_push / RR_pull / RR_flow semantics). Buffers: [stream][frame][channel] with
   // `stream_stride` frames between streams (ignored when there is one stream).
@@ -60,6 +65,8 @@ public:
   // optional per-kernel timing: HIP events recorded on the launch stream around every stage launch
   void set_profiling(bool on);
   int read_profile(double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches);
+  // same records aggregated per kernel, as JSON: [{"kernel": "...", "hot": 0|1, "launches": n, "ms": t}, ...]; clears them
+  int read_profile_json(std::string &out);
 
 private:
   Engine() = default;
@@ -75,6 +82,8 @@ private:
 
   int feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
            size_t *direct_out);
+  int feed_impl(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
+                size_t *direct_out);
   int advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout);
   int ensure_ring(int f, long long live_needed);
   int copy_out(float *dst, size_t stride_frames, size_t frames, bool to_host);
@@ -88,8 +97,14 @@ private:
 
   ChainPlan plan_;
   int nch_ = 0, S_ = 0, C_ = 0;
-  hipStream_t stream_ = nullptr;
-  bool own_stream_ = false;
+  hipStream_t stream_ = nullptr; // where work is queued: own_ or the caller's (RRX_set_stream)
+  hipStream_t own_ = nullptr;    // created by init, destroyed by the destructor; never the caller's
+  hipEvent_t ev_switch_ = nullptr;
+  // A failure after the counters of a push / drain started moving leaves them skewed against the device fifos:
+  // the handle is then poisoned and every later data call returns kInternal (rate_uni.c has no recovery either).
+  bool poisoned_ = false;
+  int fail(int rc) { if (rc != kOk) poisoned_ = true; return rc; }
+  int dev_alloc(void **p, size_t bytes);
   // side stream for the seam kernels: seam(k) only depends on fused(k), so it runs beside fused(k+1)
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fused_ = nullptr, ev_seam_[2] = {nullptr, nullptr};
@@ -119,10 +134,11 @@ private:
   struct PolyMf { double *cfm = nullptr; FusedBlock *blk = nullptr; int KS = 0, NGRP = 0, Vt = 0, blk_cap = 0; };
   std::vector<PolyMf> polymf_;
   struct Pending { long long B0 = 0; int nblocks = 0; };
-  struct ProfRec { hipEvent_t e0, e1; bool hot; };
+  struct ProfRec { hipEvent_t e0, e1; bool hot; const char *name; };
   std::vector<ProfRec> prof_;
   bool profiling_ = false;
-  int prof_begin(bool hot);
+  int prof_begin(bool hot, const char *name = "");
+  void prof_name(int idx, const char *name) { if (idx >= 0 && name) prof_[idx].name = name; }
   void prof_end(int idx);
   int dbg_ = 0;           // RSMP_DBG ablation bits (0 in production)
   bool no_side_ = false;  // RSMP_NO_SIDE: keep seam kernels on the main stream
@@ -131,5 +147,7 @@ private:
   size_t stage_floats_ = 0;
   size_t slab_frames_ = 0;
 };
+
+bool device_is_gfx950(); // current HIP device runs gfx950 code objects
 
 } // namespace rsmp

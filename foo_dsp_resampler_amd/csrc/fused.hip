@@ -658,15 +658,24 @@ bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_o
   return n >= 4 && n <= 32 && span <= kSpanMax && max_seam_outputs <= 64;
 }
 
-#define RSMP_FUSED_CASE(n, p) \
-  if (log2n == n && log2p == p) return launch_fused_t<n, p, 2, kSpanMax, false>(in, out, a, st);
-#define RSMP_FUSED_EXACT(n, p, sp) \
-  if (log2n == n && log2p == p && a.span == sp) return launch_fused_t<n, p, 2, sp, false>(in, out, a, st);
-#define RSMP_FUSED_MF(n, p, ks) \
-  if (log2n == n && log2p == p && a.KS == ks) return launch_fused_t<n, p, 2, ks, true>(in, out, a, st);
+#define RSMP_FUSED_CASE(n, p)                                                     \
+  if (log2n == n && log2p == p) {                                                 \
+    if (kname) *kname = "rsmp::fused_kernel<" #n ", " #p ", 2, 32, false>";       \
+    return launch_fused_t<n, p, 2, kSpanMax, false>(in, out, a, st);              \
+  }
+#define RSMP_FUSED_EXACT(n, p, sp)                                                \
+  if (log2n == n && log2p == p && a.span == sp) {                                 \
+    if (kname) *kname = "rsmp::fused_kernel<" #n ", " #p ", 2, " #sp ", false>";  \
+    return launch_fused_t<n, p, 2, sp, false>(in, out, a, st);                    \
+  }
+#define RSMP_FUSED_MF(n, p, ks)                                                   \
+  if (log2n == n && log2p == p && a.KS == ks) {                                   \
+    if (kname) *kname = "rsmp::fused_kernel<" #n ", " #p ", 2, " #ks ", true>";   \
+    return launch_fused_t<n, p, 2, ks, true>(in, out, a, st);                     \
+  }
 
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
-                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
+                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st, const char **kname)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   if (a.cfm) { // polyphase on the matrix pipe

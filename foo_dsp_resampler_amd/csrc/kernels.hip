@@ -496,14 +496,17 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
   return hipGetLastError();
 }
 
-#define RSMP_DFT_CASE(n, p, d) \
-  if (log2n == n && log2p == p && log2nd == d) return launch_dft_t<n, p, d>(in, out, a, st);
-#define RSMP_DFT_SIZE(n)    \
-  RSMP_DFT_CASE(n, n, n)     \
-  RSMP_DFT_CASE(n, n - 1, n) \
-  RSMP_DFT_CASE(n, n - 2, n) \
-  RSMP_DFT_CASE(n, n, n - 1) \
-  RSMP_DFT_CASE(n, n, n - 2)
+#define RSMP_DFT_CASE(n, p, d)                                         \
+  if (log2n == n && log2p == p && log2nd == d) {                       \
+    if (kname) *kname = "rsmp::dft_kernel<" #n ", " #p ", " #d ">";    \
+    return launch_dft_t<n, p, d>(in, out, a, st);                      \
+  }
+#define RSMP_DFT_SIZE(n, n1, n2) \
+  RSMP_DFT_CASE(n, n, n)          \
+  RSMP_DFT_CASE(n, n1, n)         \
+  RSMP_DFT_CASE(n, n2, n)         \
+  RSMP_DFT_CASE(n, n, n1)         \
+  RSMP_DFT_CASE(n, n, n2)
 
 bool dft_shape_supported(int log2n, int log2p, int log2nd)
 {
@@ -513,19 +516,22 @@ bool dft_shape_supported(int log2n, int log2p, int log2nd)
 }
 
 hipError_t launch_dft(int log2n, int log2p, int log2nd, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
-                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st)
+                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st, const char **kname)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
-  RSMP_DFT_SIZE(11)
-  RSMP_DFT_SIZE(12)
-  RSMP_DFT_SIZE(13)
-  RSMP_DFT_SIZE(14)
+  RSMP_DFT_SIZE(11, 10, 9)
+  RSMP_DFT_SIZE(12, 11, 10)
+  RSMP_DFT_SIZE(13, 12, 11)
+  RSMP_DFT_SIZE(14, 13, 12)
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                       const F64View &dd, const PolyArgs &a, hipStream_t st)
+                       const F64View &dd, const PolyArgs &a, hipStream_t st, const char **kname)
 {
+  static const char *const names[2][4] = {{"rsmp::poly_kernel<0>", "rsmp::poly_kernel<1>", "rsmp::poly_kernel<2>", "rsmp::poly_kernel<3>"},
+                                          {"", "rsmp::poly_coop_kernel<1>", "rsmp::poly_coop_kernel<2>", "rsmp::poly_coop_kernel<3>"}};
+  if (kname && order >= 0 && order <= 3) *kname = names[(order >= 1 && a.coop) ? 1 : 0][order];
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const long long tiles = (a.count + a.tile - 1) / a.tile;
   dim3 grid((unsigned)tiles, a.C), block(256);
@@ -562,8 +568,11 @@ hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32
 }
 
 hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                       const F64View &dd, const HalfArgs &a, hipStream_t st)
+                       const F64View &dd, const HalfArgs &a, hipStream_t st, const char **kname)
 {
+  static const char *const names[6] = {"rsmp::half_kernel<8>", "rsmp::half_kernel<9>", "rsmp::half_kernel<10>",
+                                       "rsmp::half_kernel<11>", "rsmp::half_kernel<12>", "rsmp::half_kernel<13>"};
+  if (kname && a.ncoef >= 8 && a.ncoef <= 13) *kname = names[a.ncoef - 8];
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const long long tiles = (a.count + kHalfTile - 1) / kHalfTile;
   dim3 grid((unsigned)tiles, a.C), block(256);

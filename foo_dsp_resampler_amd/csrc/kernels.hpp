@@ -140,16 +140,17 @@ struct HalfArgs {
   double coef[13];
 };
 
-// returns hipSuccess or the launch error; `split` selects the 16384-point 8-byte exchange mode
+// All launchers return hipSuccess or the launch error; `kname` (optional) receives the name of the kernel instance
+// that was picked, as rocprofv3 prints it (static string).
 hipError_t launch_dft(int log2n, int log2p, int log2nd, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
-                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st);
+                      const F32View &df, const F64View &dd, const DftArgs &a, hipStream_t st, const char **kname = nullptr);
 hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                       const F64View &dd, const PolyArgs &a, hipStream_t st);
+                       const F64View &dd, const PolyArgs &a, hipStream_t st, const char **kname = nullptr);
 hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                       const F64View &dd, const HalfArgs &a, hipStream_t st);
+                       const F64View &dd, const HalfArgs &a, hipStream_t st, const char **kname = nullptr);
 bool dft_shape_supported(int log2n, int log2p, int log2nd);
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
-                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
+                        const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st, const char **kname = nullptr);
 // seam_kernel: the outputs whose window straddles two blocks; launch after launch_fused on the same stream
 hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st);
 bool fused_shape_supported(int log2n, int log2p, int n, int span, int max_seam_outputs);
@@ -168,7 +169,7 @@ struct PolyMfArgs {
 };
 bool polymf_supported(int ksteps);
 hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                         const F64View &dd, const PolyMfArgs &a, hipStream_t st);
+                         const F64View &dd, const PolyMfArgs &a, hipStream_t st, const char **kname = nullptr);
 // element-wise copy of absolute range [a0, a1) of every channel from one fifo view to another
 // (ring regrow, carrying the unconsumed tail of an in-place push into the ring, device pulls)
 hipError_t launch_copy(bool f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd, long long a0,

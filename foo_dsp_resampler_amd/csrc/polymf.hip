@@ -181,8 +181,9 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
 bool polymf_supported(int ksteps) { return ksteps >= 7 && ksteps <= 9; }
 
 hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
-                         const F64View &dd, const PolyMfArgs &a, hipStream_t st)
+                         const F64View &dd, const PolyMfArgs &a, hipStream_t st, const char **kname)
 {
+  if (kname) *kname = ksteps == 7 ? "rsmp::polymf_kernel<7>" : ksteps == 8 ? "rsmp::polymf_kernel<8>" : "rsmp::polymf_kernel<9>";
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const size_t lds_bytes = size_t(kPmPad + a.Vt + a.n + 4 + kPmPad) * 16;
   dim3 grid(a.nblocks * ((a.C + 1) / 2)), block(256);

@@ -13,10 +13,8 @@ RR_BEST, RR_NORM = 0, 1
 EXPECTED_SYMBOLS = [
     "init_ratelib", "close_ratelib", "RR_open", "RR_flow", "RR_push", "RR_pull", "RR_drain", "RR_close", "RR_strerror",
     "RRX_open_batch", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
-    "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
+    "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_profile_report", "RRX_debug_fail_alloc", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
     "RRX_describe_plan", "RRX_plan_table",
-    "DSPR_create", "DSPR_destroy", "DSPR_on_chunk", "DSPR_end_of_track", "DSPR_flush", "DSPR_get_latency",
-    "DSPR_peek_output", "DSPR_pop_output", "DSPR_lpc_extrapolate",
 ]
 
 
@@ -40,8 +38,14 @@ _lib = None
 _ALLOC_CB = C.CFUNCTYPE(None)
 
 
+alloc_handler_calls = 0  # how often the library ran the registered allocation-failure handler (xmalloc.c:38-43)
+
+
 def _alloc_failed():
-    raise MemoryError("ratelib allocation failure")
+    # The plugin's handler throws std::bad_alloc through the C frames; a Python callback cannot unwind C, so this one
+    # only counts -- the failing call still returns RR_ENOMEM, which _check() raises as RRError.
+    global alloc_handler_calls
+    alloc_handler_calls += 1
 
 
 _alloc_cb = _ALLOC_CB(_alloc_failed)
@@ -101,22 +105,14 @@ def lib():
         L.RRX_sync.argtypes = [vp]
         L.RRX_profile.argtypes = [vp, C.c_int]
         L.RRX_profile_read.argtypes = [vp, P(C.c_double), P(C.c_longlong), P(C.c_double), P(C.c_longlong)]
+        L.RRX_profile_report.argtypes = [vp, C.c_char_p, sz]
+        L.RRX_debug_fail_alloc.argtypes = [C.c_int]
+        L.RRX_debug_fail_alloc.restype = None
         for n in ("RRX_isamp_max", "RRX_available"):
             getattr(L, n).argtypes = [vp]
             getattr(L, n).restype = sz
         L.RRX_channels.argtypes = [vp]
         L.RRX_streams.argtypes = [vp]
-        L.DSPR_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(vp)]
-        L.DSPR_destroy.argtypes = [P(vp)]
-        L.DSPR_destroy.restype = None
-        L.DSPR_on_chunk.argtypes = [vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, P(C.c_int)]
-        L.DSPR_end_of_track.argtypes = [vp]
-        L.DSPR_flush.argtypes = [vp]
-        L.DSPR_flush.restype = None
-        L.DSPR_get_latency.argtypes = [vp]
-        L.DSPR_get_latency.restype = C.c_double
-        L.DSPR_peek_output.argtypes = [vp, P(sz), P(C.c_uint), P(C.c_uint)]
-        L.DSPR_pop_output.argtypes = [vp, vp, sz]
         L.RRX_describe_plan.argtypes = [P(RRConfig), C.c_char_p, sz]
         L.RRX_plan_table.argtypes = [P(RRConfig), C.c_int, vp, sz, P(sz)]
         _lib = L
@@ -220,6 +216,14 @@ class Resampler:
         _check(self.L.RRX_profile_read(self.h, C.byref(hm), C.byref(hn), C.byref(om), C.byref(on)), "RRX_profile_read")
         return {"hot_ms": hm.value, "hot_launches": hn.value, "other_ms": om.value, "other_launches": on.value}
 
+    def profile_report(self):
+        """Per-kernel records since the last read: [{"kernel", "hot", "launches", "ms"}, ...]."""
+        buf = C.create_string_buffer(1 << 14)
+        n = self.L.RRX_profile_report(self.h, buf, len(buf))
+        if n < 0:
+            raise RRError(-n, "RRX_profile_report")
+        return json.loads(buf.value.decode())
+
     # -- host API (RR_push / RR_pull / RR_flow / RR_drain)
     def _host_in(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -301,55 +305,3 @@ class Resampler:
                                       in_stride or in_frames, C.c_void_p(tout.data_ptr()), out_stride or out_cap,
                                       in_frames, out_cap, C.byref(iu), C.byref(og)), "RRX_flow_device")
         return iu.value, og.value
-
-
-class DspRate:
-    """Mirror of the plugin's dsp_rate object (foo_dsp_rate.h:24-80) through the DSPR_* entry points."""
-
-    def __init__(self, out_rate, quality=RR_BEST, allow_aliasing=0, passband10=950, phase=50):
-        _ensure_init()
-        self.L = lib()
-        self.h = C.c_void_p()
-        _check(self.L.DSPR_create(out_rate, quality, allow_aliasing, passband10, phase, C.byref(self.h)), "DSPR_create")
-
-    def close(self):
-        if getattr(self, "h", None) is not None and self.h:
-            self.L.DSPR_destroy(C.byref(self.h))
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def _drain_queue(self):
-        chunks = []
-        while True:
-            n, ch, sr = C.c_size_t(0), C.c_uint(0), C.c_uint(0)
-            self.L.DSPR_peek_output(self.h, C.byref(n), C.byref(ch), C.byref(sr))
-            if n.value == 0:
-                break
-            buf = np.empty((n.value, ch.value), dtype=np.float32)
-            _check(self.L.DSPR_pop_output(self.h, buf.ctypes.data, n.value), "DSPR_pop_output")
-            chunks.append((buf, sr.value))
-        return chunks
-
-    def on_chunk(self, x, sample_rate, channel_config=3):
-        """Returns (passthrough, [(frames array, sample_rate), ...])."""
-        x = np.ascontiguousarray(x, dtype=np.float32)
-        x = x.reshape(x.shape[0], -1)
-        p = C.c_int(0)
-        _check(self.L.DSPR_on_chunk(self.h, x.ctypes.data, x.shape[0], x.shape[1], sample_rate, channel_config,
-                                    C.byref(p)), "DSPR_on_chunk")
-        return bool(p.value), self._drain_queue()
-
-    def end_of_track(self):
-        _check(self.L.DSPR_end_of_track(self.h), "DSPR_end_of_track")
-        return self._drain_queue()
-
-    def flush(self):
-        self.L.DSPR_flush(self.h)
-
-    @property
-    def latency(self):
-        return self.L.DSPR_get_latency(self.h)

@@ -37,8 +37,10 @@ int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, f
 int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp);
 int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen);
 
-/* Use the caller's hipStream_t (passed as void*) for all work of this handle; NULL restores the
- * handle's own stream.  RRX_sync blocks until everything enqueued so far has finished. */
+/* Use the caller's hipStream_t (passed as void*) for all work of this handle from now on; NULL restores the
+ * handle's own stream.  The caller keeps ownership of its stream (RR_close never destroys it); work already queued
+ * on the previous stream is ordered before the work queued after the switch.  RRX_sync blocks until everything
+ * enqueued so far has finished. */
 int RRX_set_stream(RR_handle *h, void *hip_stream);
 int RRX_sync(RR_handle *h);
 
@@ -48,6 +50,17 @@ int RRX_sync(RR_handle *h);
  * stage kernels, and clears the records. */
 int RRX_profile(RR_handle *h, int enable);
 int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches);
+/* The same records per kernel instance, as JSON text: [{"kernel": "rsmp::fused_kernel<12, 11, 2, 7, true>", "hot": 1,
+ * "launches": n, "ms": t}, ...] with the names rocprofv3 prints, so a benchmark line can say which variant the
+ * engine's dispatch picked.  Synchronises and clears the records.  Returns the length written (text is truncated
+ * to cap-1 bytes) or the negated RR_error. */
+int RRX_profile_report(RR_handle *h, char *buf, size_t cap);
+
+/* Test hook (fault injection): the nth device allocation from now on, counted process-wide, fails as if the GPU were
+ * out of memory (RR_ENOMEM + the init_ratelib handler, rate/xmalloc.c:38-43); 0 disarms.  A failure in the middle of a
+ * push or drain poisons the handle: every later data call returns RR_INTERNAL until it is closed (its counters no
+ * longer describe the device fifos; the reference has no recovery path either, chain.h:26-29 tears the chain down). */
+void RRX_debug_fail_alloc(int nth);
 
 /* Introspection: isamp_max of rate_base.h:531, frames currently pullable (fifo_occupancy of the last
  * fifo, rate_base.h:447-448), shape of the handle. */
@@ -66,28 +79,6 @@ int RRX_describe_plan(const RR_config *config, char *buf, size_t cap);
  * which = 2 -> polyphase table [phase][tap][order+1] (rate/prepare_coefs.h:20-46).  *count receives
  * the full length.  Returns RR_OK or RR_INVPARAM. */
 int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, size_t *count);
-
-/* ---- plugin layer (host side of foo_dsp_rate.cpp, restated over plain buffers) -------------------------
- * Mirrors class dsp_rate (foo_dsp_rate.h:24-80): chunk staging, LPC extrapolation of the track edges on
- * the host (lpc/lpc.cpp), pre-roll dropping, latency accounting; the resampling itself goes through RR_*.
- * out_rate follows RateConfig::outRate (dsp_config.h:60-95): Hz, or -2/-5 (x2/x4), -3/-4 (/2, /4). */
-typedef struct DSPR_handle_tag DSPR_handle;
-int DSPR_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase, DSPR_handle **h);
-void DSPR_destroy(DSPR_handle **h);
-/* dsp_rate::on_chunk (foo_dsp_rate.cpp:130-210): *passthrough = 1 when the chunk needs no resampling and
- * must be forwarded untouched; otherwise it is consumed and output chunks are queued. Returns RR_error. */
-int DSPR_on_chunk(DSPR_handle *h, const fb_sample_t *data, size_t frames, unsigned channels, unsigned sample_rate,
-                  unsigned channel_config, int *passthrough);
-int DSPR_end_of_track(DSPR_handle *h); /* on_endoftrack / on_endofplayback -> flushwrite, foo_dsp_rate.cpp:80-82,218-313 */
-void DSPR_flush(DSPR_handle *h);       /* dsp_rate::flush, foo_dsp_rate.cpp:212-216 */
-double DSPR_get_latency(const DSPR_handle *h); /* foo_dsp_rate.cpp:315-322 */
-/* Output chunks queued so far (what the plugin hands to insert_chunk): peek the oldest one's shape, then pop
- * it into `dst` (frames * channels floats). */
-int DSPR_peek_output(const DSPR_handle *h, size_t *frames, unsigned *channels, unsigned *sample_rate);
-int DSPR_pop_output(DSPR_handle *h, fb_sample_t *dst, size_t cap_frames);
-/* The host-side LPC edge extrapolator the plugin layer uses, with the signature of lpc_extrapolate2
- * (lpc/lpc.h:25): writes extra_bkwd frames before data[0] and extra_fwd frames after data[data_len*nch). */
-void DSPR_lpc_extrapolate(fb_sample_t *data, size_t data_len, int nch, int lpc_order, size_t extra_bkwd, size_t extra_fwd);
 
 #ifdef __cplusplus
 }

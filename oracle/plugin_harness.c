@@ -1,9 +1,14 @@
-/* plugin_oracle.c -- CPU restatement of the plugin layer above the ratelib.h ABI:
- * dsp_rate::on_chunk / flushwrite / get_latency (foo_dsp_rate.cpp) with the LPC edge extrapolation of
- * lpc/lpc.cpp, driving the CPU oracle (rate_oracle.c).  TEST INFRASTRUCTURE ONLY, like rate_oracle.c, and
- * equally "parity unpinned": the reference ships no fixture for this path and SURVEY.md records no probe of
- * it, so it is checked for internal consistency only (lengths, latency, edge continuity) and serves as the
- * independent second implementation the GPU plugin layer is compared with.
+/* plugin_harness.c -- the caller side of the ratelib.h ABI as ONE test harness: the chunk logic of
+ * dsp_rate::on_chunk / flushwrite / get_latency (foo_dsp_rate.cpp:84-322) with the LPC edge extrapolation of
+ * lpc/lpc.cpp, written once over a table of {open, push, pull, drain, close} function pointers (orc_rr_api).
+ * The tests run the SAME harness over the CPU oracle (orc_*, the default table) and over the product's
+ * RR_* entry points (libratelib_amd.so, table filled in by tests/oracle_binding.py), so what is compared is the
+ * resampler behind the ABI under the plugin's real call pattern (small chunks, pre-roll drop, three flush
+ * cases), not two copies of the chunk logic.
+ * TEST INFRASTRUCTURE ONLY, like rate_oracle.c; nothing of it is linked into the product library.
+ * The chunk logic itself is "parity unpinned" (foo_dsp_rate.cpp needs the foobar2000 SDK, the reference ships
+ * no fixture for it); the LPC arithmetic IS pinned on the reference's own lpc/lpc.cpp
+ * (tests/golden/lpc_reference_vectors.npz, tests/test_lpc_reference.py).
  */
 #include "rate_oracle.h"
 
@@ -141,9 +146,19 @@ typedef struct {
   unsigned ch, rate;
 } out_chunk;
 
+/* the five ratelib.h entry points the plugin binds (chain.h:36-40); handles are opaque */
+static int api_open(const orc_config *c, int nch, void **h) { return orc_open(c, nch, (orc_handle **)h); }
+static int api_push(void *h, const float *i, size_t n) { return orc_push((orc_handle *)h, i, n); }
+static int api_pull(void *h, float *o, size_t n, size_t *g) { return orc_pull((orc_handle *)h, o, n, g); }
+static int api_drain(void *h) { return orc_drain((orc_handle *)h); }
+static void api_close(void **h) { orc_close((orc_handle **)h); }
+static const orc_rr_api oracle_api = {api_open, api_push, api_pull, api_drain, api_close};
+
 typedef struct orc_dsp {
   int out_rate_cfg, quality, allow_aliasing, passband10, phase; /* RateConfig, dsp_config.h:71-111 */
-  orc_handle *h;
+  orc_rr_api api;
+  int err;   /* first non-zero RR_error of the current entry-point call (chain.h:26-29 raises per call) */
+  void *h;
   size_t in_accum, out_accum;
   float *in0, *in, *outb;
   size_t inbuf0, inbuf, outbuf, prime;
@@ -180,9 +195,11 @@ static void emit(orc_dsp *d, const float *frames, size_t n)
   c->frames = n; c->ch = d->ch; c->rate = d->out_rate;
 }
 
+static void note(orc_dsp *d, int rc) { if (rc && !d->err) d->err = rc; }
+
 static void dsp_close(orc_dsp *d) /* :123-128 */
 {
-  orc_close(&d->h);
+  d->api.close(&d->h);
   d->in_accum = d->out_accum = 0;
 }
 
@@ -194,7 +211,7 @@ static void reinit(orc_dsp *d, unsigned rate, unsigned ch, unsigned chmask) /* :
   d->out_rate = realrate(d, rate);
   c.in_rate = rate; c.out_rate = d->out_rate; c.phase = (double)d->phase;
   c.bandwidth = (double)d->passband10 / 10.0; c.allow_aliasing = d->allow_aliasing ? 1 : 0; c.quality = d->quality;
-  orc_open(&c, (int)ch, &d->h);
+  note(d, d->api.open(&c, (int)ch, &d->h));
   d->ch = ch; d->chmask = chmask; d->rate = rate;
   d->in_accum = d->out_accum = 0;
   d->held = 0; d->dropped = 0; d->pre = 0;
@@ -222,10 +239,10 @@ static void flushwrite(orc_dsp *d) /* :218-313 */
   size_t got, avail;
   if (!d->h) return;
   if (!d->pre && !(d->held > 2 * LPC_ORDER)) { /* too short to extrapolate */
-    orc_push(d->h, d->in, d->held);
-    orc_drain(d->h);
+    note(d, d->api.push(d->h, d->in, d->held));
+    note(d, d->api.drain(d->h));
     for (;;) {
-      orc_pull(d->h, d->outb, d->outbuf, &got);
+      got = 0; note(d, d->api.pull(d->h, d->outb, d->outbuf, &got));
       if (!got) break;
       d->out_accum += got;
       emit(d, d->outb, got);
@@ -238,13 +255,13 @@ static void flushwrite(orc_dsp *d) /* :218-313 */
     lpc_extrapolate(d->in, prime, (int)d->ch, LPC_ORDER, d->n_add, 0);
     lpc_extrapolate(d->in + (d->held - prime) * d->ch, prime, (int)d->ch, LPC_ORDER, 0, d->n_add);
     d->pre = 1;
-    orc_push(d->h, d->in0, d->n_add + d->held + d->n_add);
-    orc_drain(d->h);
+    note(d, d->api.push(d->h, d->in0, d->n_add + d->held + d->n_add));
+    note(d, d->api.drain(d->h));
     d->dropped = 0;
     d->held = 0;
     for (;;) {
       size_t drop;
-      orc_pull(d->h, d->outb + d->held * d->ch, d->outbuf - d->held, &got);
+      got = 0; note(d, d->api.pull(d->h, d->outb + d->held * d->ch, d->outbuf - d->held, &got));
       if (!got) break;
       drop = zmin(d->n_drop - d->dropped, got);
       if (drop) {
@@ -266,11 +283,11 @@ static void flushwrite(orc_dsp *d) /* :218-313 */
   }
   /* steady state reached earlier: extrapolate forward from the retained tail */
   lpc_extrapolate(d->in + (d->inbuf - d->prime) * d->ch, d->prime, (int)d->ch, LPC_ORDER, 0, d->n_add);
-  orc_push(d->h, d->in + d->inbuf * d->ch, d->n_add);
-  orc_drain(d->h);
+  note(d, d->api.push(d->h, d->in + d->inbuf * d->ch, d->n_add));
+  note(d, d->api.drain(d->h));
   d->held = 0;
   for (;;) {
-    orc_pull(d->h, d->outb + d->held * d->ch, d->outbuf - d->held, &got);
+    got = 0; note(d, d->api.pull(d->h, d->outb + d->held * d->ch, d->outbuf - d->held, &got));
     if (!got) break;
     d->held += got;
     avail = d->held - zmin(d->held, d->n_drop);
@@ -284,9 +301,10 @@ static void flushwrite(orc_dsp *d) /* :218-313 */
   dsp_close(d);
 }
 
-orc_dsp *orc_dsp_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase)
+orc_dsp *orc_dsp_create_on(const orc_rr_api *api, int out_rate, int quality, int allow_aliasing, int passband10, int phase)
 {
   orc_dsp *d = (orc_dsp *)calloc(1, sizeof(*d));
+  d->api = api ? *api : oracle_api;
   d->out_rate_cfg = out_rate; d->quality = quality; d->allow_aliasing = allow_aliasing;
   d->passband10 = passband10; d->phase = phase;
   return d;
@@ -298,6 +316,14 @@ static void clear_out(orc_dsp *d)
   for (i = 0; i < d->nout; ++i) free(d->out[i].data);
   d->nout = 0;
 }
+
+orc_dsp *orc_dsp_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase)
+{
+  return orc_dsp_create_on(NULL, out_rate, quality, allow_aliasing, passband10, phase);
+}
+
+/* RR_error raised during the last on_chunk / end_of_track call (0 = none) */
+int orc_dsp_last_error(const orc_dsp *d) { return d->err; }
 
 void orc_dsp_destroy(orc_dsp *d)
 {
@@ -311,6 +337,7 @@ void orc_dsp_destroy(orc_dsp *d)
 int orc_dsp_on_chunk(orc_dsp *d, const float *cur, size_t count, unsigned ch, unsigned rate, unsigned chmask)
 {
   size_t got;
+  d->err = 0;
   if (!d->h) {
     if ((int)rate == d->out_rate_cfg) return 1;
     reinit(d, rate, ch, chmask);
@@ -328,7 +355,7 @@ int orc_dsp_on_chunk(orc_dsp *d, const float *cur, size_t count, unsigned ch, un
       if (d->held == d->inbuf) {
         lpc_extrapolate(d->in, d->prime, (int)d->ch, LPC_ORDER, d->n_add, 0);
         d->pre = 1;
-        orc_push(d->h, d->in0, d->n_add + d->inbuf);
+        note(d, d->api.push(d->h, d->in0, d->n_add + d->inbuf));
       }
     }
     if (d->pre && count) {
@@ -337,10 +364,10 @@ int orc_dsp_on_chunk(orc_dsp *d, const float *cur, size_t count, unsigned ch, un
         memcpy(d->in + (d->inbuf - count) * d->ch, cur, count * d->ch * sizeof(float));
       } else
         memcpy(d->in, cur + (count - d->inbuf) * d->ch, d->inbuf * d->ch * sizeof(float));
-      orc_push(d->h, cur, count);
+      note(d, d->api.push(d->h, cur, count));
       cur += count * d->ch; d->in_accum += count; count = 0;
     }
-    orc_pull(d->h, d->outb, d->outbuf, &got);
+    got = 0; note(d, d->api.pull(d->h, d->outb, d->outbuf, &got));
     drop = d->n_drop - d->dropped;
     if (drop) {
       drop = zmin(drop, got);
@@ -359,7 +386,7 @@ int orc_dsp_on_chunk(orc_dsp *d, const float *cur, size_t count, unsigned ch, un
   return 0;
 }
 
-void orc_dsp_end_of_track(orc_dsp *d) { flushwrite(d); }
+void orc_dsp_end_of_track(orc_dsp *d) { d->err = 0; flushwrite(d); }
 void orc_dsp_flush(orc_dsp *d) { if (d->h) dsp_close(d); } /* :212-216 */
 
 double orc_dsp_latency(const orc_dsp *d) /* :315-322 */

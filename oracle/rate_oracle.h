@@ -96,6 +96,27 @@ void orc_free(void *p);
  * isgn=-1: inverse, unnormalised (returns n/2 times the signal). n = power of two >= 4. */
 void orc_rdft(int n, int isgn, double *a);
 
+/* ---- caller-side harness (plugin_harness.c): the plugin's chunk logic over a table of ABI entry points ---- */
+typedef struct {
+  int (*open)(const orc_config *cfg, int nchannels, void **handle);  /* RR_open, rate/ratelib.h:74 (RR_config has orc_config's layout) */
+  int (*push)(void *handle, const float *ibuf, size_t isamp);        /* RR_push, :76 */
+  int (*pull)(void *handle, float *obuf, size_t osamp, size_t *ogen); /* RR_pull, :77 */
+  int (*drain)(void *handle);                                         /* RR_drain, :78 */
+  void (*close)(void **handle);                                       /* RR_close, :79 */
+} orc_rr_api;
+
+typedef struct orc_dsp orc_dsp;
+/* api == NULL: the CPU oracle's orc_* functions */
+orc_dsp *orc_dsp_create_on(const orc_rr_api *api, int out_rate, int quality, int allow_aliasing, int passband10, int phase);
+orc_dsp *orc_dsp_create(int out_rate, int quality, int allow_aliasing, int passband10, int phase);
+void orc_dsp_destroy(orc_dsp *d);
+int orc_dsp_on_chunk(orc_dsp *d, const float *cur, size_t count, unsigned ch, unsigned rate, unsigned chmask); /* 1 = pass-through */
+void orc_dsp_end_of_track(orc_dsp *d);
+void orc_dsp_flush(orc_dsp *d);
+double orc_dsp_latency(const orc_dsp *d);
+int orc_dsp_last_error(const orc_dsp *d);
+void orc_lpc_extrapolate(float *data, size_t data_len, int nch, int order, size_t extra_bkwd, size_t extra_fwd);
+
 #ifdef __cplusplus
 }
 #endif

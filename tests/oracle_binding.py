@@ -32,7 +32,7 @@ class OrcDesignCall(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("rate_oracle.c", "plugin_oracle.c", "rate_oracle.h")]
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("rate_oracle.c", "plugin_harness.c", "rate_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")],
                               stdout=subprocess.DEVNULL)
@@ -77,6 +77,9 @@ def lib():
         L.orc_kaiser_beta.restype = C.c_double
         L.orc_dsp_create.argtypes = [C.c_int] * 5
         L.orc_dsp_create.restype = C.c_void_p
+        L.orc_dsp_create_on.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.orc_dsp_create_on.restype = C.c_void_p
+        L.orc_dsp_last_error.argtypes = [C.c_void_p]
         L.orc_dsp_destroy.argtypes = [C.c_void_p]
         L.orc_dsp_destroy.restype = None
         L.orc_dsp_on_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
@@ -210,13 +213,30 @@ class Oracle:
         return [{f[0]: getattr(arr[i], f[0]) for f in OrcDesignCall._fields_} for i in range(n)]
 
 
-class OracleDsp:
-    """CPU restatement of the plugin's dsp_rate object (oracle/plugin_oracle.c); same call shapes as
-    foo_dsp_resampler_amd.DspRate."""
+class RrApi(C.Structure):
+    """orc_rr_api: the five ratelib.h entry points the plugin binds (chain.h:36-40)."""
+    _fields_ = [("open", C.c_void_p), ("push", C.c_void_p), ("pull", C.c_void_p), ("drain", C.c_void_p),
+                ("close", C.c_void_p)]
 
-    def __init__(self, out_rate, quality=0, allow_aliasing=0, passband10=950, phase=50):
+
+def product_api():
+    """Function table over the PRODUCT's C ABI (libratelib_amd.so: RR_open / RR_push / RR_pull / RR_drain /
+    RR_close).  Needs a GPU once anything is opened through it."""
+    import foo_dsp_resampler_amd.ratelib as R
+    R._ensure_init()
+    L = R.lib()
+    return RrApi(*[C.cast(getattr(L, n), C.c_void_p).value for n in ("RR_open", "RR_push", "RR_pull", "RR_drain", "RR_close")])
+
+
+class OracleDsp:
+    """The plugin's dsp_rate object restated as a test harness (oracle/plugin_harness.c) over a table of ABI entry
+    points: `api=None` drives the CPU oracle, `api=product_api()` drives libratelib_amd.so."""
+
+    def __init__(self, out_rate, quality=0, allow_aliasing=0, passband10=950, phase=50, api=None):
         self.L = lib()
-        self.h = self.L.orc_dsp_create(out_rate, quality, allow_aliasing, passband10, phase)
+        self._api = api  # keep the table alive (the harness copies it, but the library handle must outlive us)
+        self.h = self.L.orc_dsp_create_on(C.byref(api) if api is not None else None, out_rate, quality, allow_aliasing,
+                                          passband10, phase)
 
     def close(self):
         if self.h:
@@ -254,6 +274,15 @@ class OracleDsp:
     @property
     def latency(self):
         return self.L.orc_dsp_latency(self.h)
+
+    @property
+    def last_error(self):
+        return self.L.orc_dsp_last_error(self.h)
+
+
+def PluginOnGpu(out_rate, **kw):
+    """The same harness over the product's RR_* entry points."""
+    return OracleDsp(out_rate, api=product_api(), **kw)
 
 
 def lcg_noise(n_frames, nch, seed):

@@ -1,12 +1,15 @@
-"""Plugin layer (dsp_rate::on_chunk / flushwrite / get_latency + LPC edge extrapolation).
+"""Plugin call pattern (dsp_rate::on_chunk / flushwrite / get_latency + LPC edge extrapolation).
 
-CPU part: the oracle's restatement alone (lengths, latency accounting, edges) -- there is no reference
-fixture for this path, so these are consistency checks.  GPU part: the host-side C++ mirror
-(foo_dsp_resampler_amd.DspRate, through DSPR_*) against the oracle restatement, chunk for chunk."""
+ONE chunk-logic harness (oracle/plugin_harness.c, test infrastructure) parameterised by a table of
+{open, push, pull, drain, close} entry points.  CPU part: the harness over the oracle's orc_* functions
+(lengths, latency accounting, edges) -- there is no reference fixture for this path, so these are consistency
+checks.  GPU part: the same harness over the product's RR_* entry points (libratelib_amd.so) against the run
+over the oracle, chunk for chunk: same chunking, same frame counts, same latency values, samples within the
+parity bar -- i.e. the resampler behind the ABI behaves identically under the plugin's real call pattern."""
 import numpy as np
 import pytest
 
-from oracle_binding import OracleDsp, lcg_noise
+from oracle_binding import OracleDsp, PluginOnGpu, lcg_noise
 
 
 def music_like(n, nch, fs, seed):
@@ -88,10 +91,11 @@ def test_oracle_plugin_format_change_flushes():
     (48000, 44100, 6, 60000, [2048, 4095]),              # 5.1
 ])
 def test_gpu_plugin_layer_matches_oracle(fs, fo, nch, n, sizes):
-    import foo_dsp_resampler_amd as F
     from parity import assert_parity
     x = music_like(n, nch, fs, 7)
-    got, lat_g = run_track(F.DspRate(fo), x, fs, sizes)
+    gpu = PluginOnGpu(fo)
+    got, lat_g = run_track(gpu, x, fs, sizes)
+    assert gpu.last_error == 0
     ref, lat_r = run_track(OracleDsp(fo), x, fs, sizes)
     assert [c.shape for c, _ in got] == [c.shape for c, _ in ref]      # same chunking, same frame counts
     assert [r for _, r in got] == [r for _, r in ref]
@@ -102,9 +106,8 @@ def test_gpu_plugin_layer_matches_oracle(fs, fo, nch, n, sizes):
 
 @pytest.mark.gpu
 def test_gpu_plugin_layer_format_change_and_passthrough():
-    import foo_dsp_resampler_amd as F
     from parity import assert_parity
-    g, o = F.DspRate(48000), OracleDsp(48000)
+    g, o = PluginOnGpu(48000), OracleDsp(48000)
     seq = [(music_like(30000, 2, 44100, 4), 44100), (np.zeros((64, 2), np.float32), 48000),
            (music_like(20000, 1, 32000, 5), 32000)]
     for x, fs in seq:
@@ -117,3 +120,45 @@ def test_gpu_plugin_layer_format_change_and_passthrough():
     assert [c.shape for c, _ in tg] == [c.shape for c, _ in to]
     for (a, _), (b, _) in zip(tg, to):
         assert_parity(a, b)
+
+
+def test_harness_reports_errors_per_call():
+    """An ABI that fails: the harness records the first RR_error of a call and forgets it on the next call
+    (chain.h:26-29 raises per call)."""
+    import ctypes as C
+    from oracle_binding import OrcConfig, RrApi, lib
+    calls = {"open": 0}
+    OPEN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p))
+    PUSH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+    PULL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t))
+    DRAIN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    CLOSE = C.CFUNCTYPE(None, C.POINTER(C.c_void_p))
+    L = lib()
+
+    def f_open(cfg, nch, out):
+        calls["open"] += 1
+        if calls["open"] == 1:
+            out[0] = None
+            return 1  # RR_ENOMEM on the first open only
+        return L.orc_open(C.cast(cfg, C.POINTER(OrcConfig)), nch, out)
+
+    fo, fp = OPEN(f_open), PUSH(lambda h, p, n: L.orc_push(h, p, n) if h else 3)
+
+    def f_pull(h, p, n, g):
+        if not h:
+            if g:
+                g[0] = 0
+            return 3
+        return L.orc_pull(h, p, n, g)
+
+    fl, fd = PULL(f_pull), DRAIN(lambda h: L.orc_drain(h) if h else 3)
+    fc = CLOSE(lambda hp: L.orc_close(hp))
+    api = RrApi(*[C.cast(f, C.c_void_p).value for f in (fo, fp, fl, fd, fc)])
+    d = OracleDsp(48000, api=api)
+    x = music_like(3000, 2, 44100, 9)
+    d.on_chunk(x, 44100)
+    assert d.last_error == 1           # the failed open is what this call reports
+    d.on_chunk(x, 44100)               # handle still NULL -> reinit succeeds now
+    assert d.last_error == 0
+    keep = (fo, fp, fl, fd, fc)        # noqa: F841  (callbacks must outlive the harness object)
+    d.close()

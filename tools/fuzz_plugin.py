@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Seeded random sweep of the plugin layer: DspRate (GPU engine behind DSPR_*) against the oracle's restatement
-of dsp_rate on identical chunk sequences -- short and long tracks, 1-6 channels, random chunk sizes."""
+"""Seeded random sweep of the plugin layer: the caller-side harness (oracle/plugin_harness.c) over the product's
+RR_* entry points against the same harness over the CPU oracle, on identical chunk sequences -- short and long tracks, 1-6 channels, random chunk sizes."""
 import os
 import sys
 
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import foo_dsp_resampler_amd as F  # noqa: E402
-from oracle_binding import OracleDsp  # noqa: E402
+from oracle_binding import OracleDsp, PluginOnGpu  # noqa: E402
 from parity import compare_f32  # noqa: E402
 from test_plugin_layer import music_like, run_track  # noqa: E402
 
@@ -27,7 +27,7 @@ def main(n_cases, seed):
         x = music_like(n, nch, fs, int(rng.randint(1, 1 << 30)))
         sizes = [int(rng.randint(1, 8193)) for _ in range(int(rng.randint(1, 8)))]
         ref, lat_r = run_track(OracleDsp(fo), x, fs, sizes)
-        got, lat_g = run_track(F.DspRate(fo), x, fs, sizes)
+        got, lat_g = run_track(PluginOnGpu(fo), x, fs, sizes)
         ok = [c.shape for c, _ in got] == [c.shape for c, _ in ref] and [r for _, r in got] == [r for _, r in ref] and lat_g == lat_r
         if ok and ref:
             yg, yr = np.concatenate([c for c, _ in got]), np.concatenate([c for c, _ in ref])
