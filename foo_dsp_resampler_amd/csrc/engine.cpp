@@ -167,8 +167,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   book_.rd.assign(ns + 1, 0);
   book_.st.assign(ns, Book::St());
   rings_.assign(ns + 1, Ring());
-  dftg_.assign(ns, DftGpu());
-  hist_.assign(ns + 1, 0);
+  big_.assign(ns, BigDft());
   for (int i = 0; i <= ns; ++i) rings_[i].f32 = (i == 0 || i == ns);
 
   double bytes_per_in_frame = 0, rate = 1;
@@ -178,21 +177,12 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     Book::St &st = book_.st[i];
     if (sp.kind == StageKind::Dft) {
       const DftFilter &f = plan_.dft[sp.filt];
-      // Overlap-save is block-size independent: blocks longer than the kernels support run as 16384-point
-      // GPU blocks (needs taps - 1 well below 16384).
-      DftGpu &dg = dftg_[i];
-      dg.Ng = f.N;
-      if (f.N > 16384) {
-        if (f.num_taps - 1 > 16384 - 2048) return kInvParam;
-        dg.Ng = 16384;
-        dg.decoupled = true;
-        hist_[i] = (16384 - (f.num_taps - 1)) / sp.L + 2;
-      }
-      const int Ng = dg.Ng;
+      const int Ng = f.N;
       const int log2n = ilog2(Ng);
       const int log2p = fdomain_up(sp.L) ? log2n - ilog2(sp.L) : log2n;
       const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
-      if (!dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
+      const bool big = log2n > 14; // the reference's long blocks: four-step transform (dftbig.hip)
+      if (big ? !big_dft_supported(log2n, log2p, log2nd) : !dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
       st.remL = sp.remL0;
       if (!d_G_[sp.filt]) { // G = DFT_N(L * h placed at (i + N - taps + 1) mod N) / N, rate_base.h:173-175
         std::vector<cplx> g(Ng);
@@ -204,7 +194,24 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         if ((rc = upload(G.data(), G.size() * sizeof(double2), &d)) != kOk) return rc;
         d_G_[sp.filt] = static_cast<double2 *>(d);
       }
-      if (!twiddles(log2p) || !twiddles(log2nd)) return kNoMem;
+      if (big) {
+        BigDft &bg = big_[i];
+        bg.on = true;
+        if (!twiddles(log2p - 4) || !twiddles(log2nd - 4)) return kNoMem;
+        std::vector<double2> tw(Ng);
+        for (int j = 0; j < Ng; ++j) {
+          const long double th = 2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)Ng;
+          tw[j] = make_double2((double)cosl(th), (double)sinl(th));
+        }
+        void *d = nullptr;
+        if ((rc = upload(tw.data(), tw.size() * sizeof(double2), &d)) != kOk) return rc;
+        bg.twN = static_cast<double2 *>(d);
+        // (block, pair) items in flight per round of the three launches: at most 256 MB per workspace
+        const int npairs = (C_ + 1) / 2;
+        bg.ws_items = int(std::max<long long>(1, std::min<long long>((256LL << 20) / (16LL * Ng), std::max(4 * npairs, 16))));
+        ALLOC_TRY(&bg.w1, size_t(bg.ws_items) * (size_t(1) << log2p) * sizeof(double2));
+        ALLOC_TRY(&bg.w2, size_t(bg.ws_items) * (size_t(1) << log2nd) * sizeof(double2));
+      } else if (!twiddles(log2p) || !twiddles(log2nd)) return kNoMem;
       double r = double(sp.L);
       if (sp.step > 0) r /= sp.step; else r /= double(1 << -sp.step);
       rate *= r;
@@ -510,6 +517,11 @@ Engine::~Engine()
     if (f.cfm) (void)hipFree(f.cfm);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
+  for (BigDft &b : big_) {
+    if (b.twN) (void)hipFree(b.twN);
+    if (b.w1) (void)hipFree(b.w1);
+    if (b.w2) (void)hipFree(b.w2);
+  }
   for (PolyMf &m : polymf_) {
     if (m.cfm) (void)hipFree(m.cfm);
     if (m.blk) (void)hipFree(m.blk);
@@ -579,7 +591,6 @@ F64View Engine::f64_view(int f) const
 int Engine::ensure_ring(int f, long long live_needed)
 {
   Ring &r = rings_[f];
-  live_needed += hist_[f]; // a decoupled dft stage re-reads up to hist_ items below the read pointer
   if (r.buf && r.cap >= live_needed) return kOk;
   { int rcj = join_side(); if (rcj) return rcj; } // seam kernels on the side stream may still write the old ring
   const long long cap = next_pow2(std::max<long long>({live_needed, r.cap * 2, 4096}));
@@ -591,7 +602,7 @@ int Engine::ensure_ring(int f, long long live_needed)
     Ring old = r;
     r.buf = nb;
     r.cap = cap;
-    const long long a0 = std::max<long long>(0, book_.rd[f] - hist_[f]), a1 = book_.wr[f];
+    const long long a0 = book_.rd[f], a1 = book_.wr[f];
     F32View sf = {}, df = {};
     F64View sd = {}, dd = {};
     if (r.f32) {
@@ -683,20 +694,19 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           int rc = ensure_ring(i + 1, dst_need(wro));
           if (rc) return rc;
         }
-        // GPU block geometry: the reference's, or (decoupled) 16384-point blocks over the same absolute stream
-        const DftGpu &dg = dftg_[i];
-        const int Ng = dg.Ng, Vg = Ng - ov;
+        const int Ng = N, Vg = V;
         const int log2n = ilog2(Ng);
         DftArgs a;
         a.G = d_G_[sp.filt];
         const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
         const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
-        a.tw_fwd = twiddles(log2p);
-        a.tw_inv = twiddles(log2nd);
-        a.tw_fwd8 = (log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
-        if (log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
-        a.tw_inv8 = (log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
-        if (log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
+        const bool big = big_[i].on;
+        a.tw_fwd = twiddles(big ? log2p - 4 : log2p);
+        a.tw_inv = twiddles(big ? log2nd - 4 : log2nd);
+        a.tw_fwd8 = (!big && log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
+        if (!big && log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
+        a.tw_inv8 = (!big && log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
+        if (!big && log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
         a.B0 = B0;
         a.out_offset = out_offset;
         a.nblocks = nblocks;
@@ -710,18 +720,24 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.in_limit = 0x7fffffffffffffffLL;
         a.clip_lo = -0x7fffffffffffffffLL;
         a.clip_hi = 0x7fffffffffffffffLL;
-        if (dg.decoupled) {
-          // filtered-stream positions the reference just made available: [Y0, Y1); GPU blocks that cover them
-          const long long Y0 = B0 * (long long)V, Y1 = (B0 + nblocks) * (long long)V;
-          const long long g0 = Y0 / Vg, g1 = (Y1 - 1) / Vg;
-          a.B0 = g0;
-          a.nblocks = int(g1 - g0 + 1);
-          a.in_limit = b.wr[i]; // a trailing GPU block may reach past the input: zeros there, its late outputs are clipped
-          // stored outputs, in stage-output index units (after any decimation)
-          const long long wr_abs0 = wro_before - out_offset, wr_abs1 = wro - out_offset;
-          a.clip_lo = wr_abs0;
-          a.clip_hi = wr_abs1;
-        }
+        if (big) {
+          const BigDft &bg = big_[i];
+          BigDftArgs ba;
+          ba.d = a;
+          ba.twN = bg.twN;
+          ba.w1 = bg.w1;
+          ba.w2 = bg.w2;
+          ba.log2n = log2n;
+          ba.log2mp = log2p - 4;
+          ba.log2md = log2nd - 4;
+          ba.fdomain_in = (log2p < log2n || L == 1) ? 1 : 0;
+          ba.item0 = 0;
+          const int pi = prof_begin(true, "rsmp::big_cols_fwd_kernel + big_rows_kernel + big_cols_inv_kernel");
+          HIP_TRY(launch_dft_big(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                                 dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), ba, bg.ws_items,
+                                 stream_));
+          prof_end(pi);
+        } else
         if (fused) { // launched together with the polyphase stage below
           pend.B0 = B0;
           pend.nblocks = nblocks;
@@ -974,7 +990,7 @@ int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, flo
   }
   { int rcj = join_side(); if (rcj) return rcj; }
   // carry the part of this push that no stage has consumed yet into ring 0
-  const long long a0 = std::max(book_.rd[0] - hist_[0], ein.begin), a1 = book_.wr[0];
+  const long long a0 = std::max(book_.rd[0], ein.begin), a1 = book_.wr[0];
   if (a1 > a0) {
     int rc = ensure_ring(0, book_.wr[0] - book_.rd[0]);
     if (rc) return rc;

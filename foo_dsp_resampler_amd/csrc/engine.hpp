@@ -120,11 +120,9 @@ private:
   double2 *d_tw_[20] = {};
   double2 *d_tw8_[20] = {}; // 8-points-per-thread plans (fft8_regs)
   // staging for host pushes / drains
-  // GPU block length of each dft stage: the reference's N, or 16384 when that is larger ("decoupled":
-  // availability still follows the reference's N, the kernels run their own absolute-anchored blocks)
-  struct DftGpu { int Ng = 0; bool decoupled = false; };
-  std::vector<DftGpu> dftg_;        // indexed by stage
-  std::vector<long long> hist_;     // per fifo: items below rd that must stay readable
+  // dft stages with the reference's long blocks (N >= 32768): four-step transform through a workspace (dftbig.hip)
+  struct BigDft { bool on = false; double2 *twN = nullptr, *w1 = nullptr, *w2 = nullptr; int ws_items = 0; };
+  std::vector<BigDft> big_;         // indexed by stage
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0;
                 double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0;

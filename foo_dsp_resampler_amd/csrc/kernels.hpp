@@ -47,10 +47,22 @@ struct DftArgs {
   int Vout;              // outputs kept per block when M == 1 (V, or the frequency-domain decimated count)
   int q;                 // inputs consumed per block (frequency-domain paths)
   int M;                 // time-domain decimation step (1 = none)
-  // decoupled mode (reference block length > 16384: the GPU runs its own, shorter blocks)
-  long long in_limit;    // input items at absolute index >= in_limit are not there yet: read as zero
-  long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored
+  long long in_limit;    // input items at absolute index >= in_limit read as zero (unused by the engine: always +inf)
+  long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored (always everything)
 };
+
+// Long blocks (N = 32768 ... 131072): N = 16 x M four-step transform in three launches through a workspace (dftbig.hip)
+struct BigDftArgs {
+  DftArgs d;             // tw_fwd / tw_inv: fft_regs tables of the forward / inverse ROW lengths
+  const double2 *twN;    // exp(+2 pi i j / N), j < N
+  double2 *w1, *w2;      // workspaces [item][16][Mp] and [item][16][Md]
+  int log2n, log2mp, log2md; // block length; forward / inverse row lengths (log2 of P/16 and Nd/16)
+  int fdomain_in;        // 1: the block is 16*Mp consecutive stage inputs (L = 1, or xL in the frequency domain); 0: zero stuffing
+  int item0;             // first (block, pair) item of this launch (filled in by launch_dft_big)
+};
+bool big_dft_supported(int log2n, int log2p, int log2nd);
+hipError_t launch_dft_big(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df, const F64View &dd,
+                          BigDftArgs a, int ws_items, hipStream_t st);
 
 // per-block output bookkeeping of the fused launch, computed on the host (64-bit divisions stay there)
 struct FusedBlock {

@@ -94,11 +94,13 @@ def test_other_chains(fi, fo, nch, kw):
 @pytest.mark.parametrize("phase", [0.0, 25.0, 75.0, 100.0])
 def test_non_linear_phase(phase):
     """phase != 50: the designed filter itself is only reproducible to ~1e-7 of its peak between two
-    correct FFT implementations (see tests/test_host_plan.py), so the bar here is relative RMS 1e-5."""
+    correct FFT implementations (see tests/test_host_plan.py).  Measured in round 2 for this pair
+    (profiles/r02_phase_parity.json): relative RMS 1.09e-6 at phase 0 / 100, 5.5e-7 at 25 / 75; the bar is 4x that
+    (tests/test_gpu_round2.py holds every measured case to 4x its own value)."""
     x, got, ref = run_both(44100, 48000, 2, 30000, chunk=8192, phase=phase)
     assert got.shape == ref.shape
     rep = compare_f32(got, ref)
-    assert rep["rel_rms"] < 1e-5, rep
+    assert rep["rel_rms"] < (4.4e-6 if phase in (0.0, 100.0) else 2.2e-6), rep
 
 
 def test_flow_equals_push_pull():
@@ -372,22 +374,11 @@ def test_concurrent_handles_on_threads():
                                    (16000, 11025), (48000, 32000), (8000, 48000), (24000, 32000)])
 def test_long_filters_reference_blocks_of_32768(fi, fo):
     """bandwidth 99 % makes the reference plan 32768-point DFT blocks for these pairs (dft_stage_init,
-    rate_base.h:171).  The engine runs them as 16384-point GPU blocks over the same absolute stream
-    (overlap-save is block-size independent) while availability still follows the reference's blocks."""
+    rate_base.h:171).  They run as the reference's own blocks (four-step transform, csrc/dftbig.hip), so the
+    normal parity bar applies to every branch, frequency-domain decimation included."""
     plan = F.describe_plan(fi, fo, bandwidth=99.0)
     big = [s for s in plan["stages"] if s["kind"] == "dft" and s["dft_length"] == 32768]
     assert big, plan
-    # A stage that decimates in the FREQUENCY domain (step_int < 0, dft_filter.h:157-188) truncates the
-    # spectrum, which equals a true decimation only up to the stop-band leakage (~ -176 dB); that residue
-    # depends on the block length and is an ABSOLUTE error (~1e-9 of full scale, whatever the sample's size), so
-    # for those shapes the bar is relative RMS 1e-8 and 2e-7 absolute instead of 1 ulp.
-    fdomain = any(s["step_int"] < 0 for s in big)
-
-    def check(a, b):
-        if not fdomain:
-            return assert_parity(a, b)
-        rep = compare_f32(a, b)
-        assert rep["rel_rms"] <= 1e-8 and rep["max_abs"] <= 2e-7, rep
     x = lcg_noise(90000, 2, 41)
     r, o = F.Resampler(fi, fo, 2, bandwidth=99.0), Oracle(fi, fo, 2, bandwidth=99.0)
     for lo in range(0, 90000, 23000):
@@ -395,11 +386,54 @@ def test_long_filters_reference_blocks_of_32768(fi, fo):
         a, b = r.pull_all(), o.pull_all()
         assert a.shape == b.shape, (lo, a.shape, b.shape)
         if a.size:
-            check(a, b)
+            assert_parity(a, b)
     r.drain(); o.drain()
     a, b = r.pull_all(), o.pull_all()
     assert a.shape == b.shape
-    check(a, b)
+    assert_parity(a, b)
+
+
+@pytest.mark.parametrize("fi,fo,bw,n", [
+    (22050, 8000, 99.5, 65536),    # L1, poly behind it
+    (16000, 8000, 99.7, 65536),    # frequency-domain /2
+    (24000, 8000, 99.5, 65536),    # time-domain decimation by 3
+    (11025, 8000, 99.5, 65536),    # x2 in the frequency domain
+    (8000, 48000, 99.5, 65536),    # zero stuffing x3 + frequency-domain /2
+    (8000, 32000, 99.5, 65536),    # x4 in the frequency domain
+    (32000, 24000, 99.5, 65536),   # zero stuffing x3 + frequency-domain /4
+    (16000, 8000, 99.9, 131072),   # the longest block the reference plans
+    (44100, 48000, 99.9, 131072),  # x2 at 131072, poly behind it
+])
+def test_long_filters_reference_blocks_of_65536_and_131072(fi, fo, bw, n):
+    """Filters of 8192 taps and more (lsx_set_dft_length, effects_i_dsp.c:64-73): reference blocks of 65536 / 131072
+    points, all branches of dft_stage_fn; several pushes, three channels (a lone channel in the last pair)."""
+    plan = F.describe_plan(fi, fo, bandwidth=bw)
+    assert any(s["kind"] == "dft" and s["dft_length"] == n for s in plan["stages"]), plan
+    frames = 150000 if n == 65536 else 330000
+    x = lcg_noise(frames, 3, 43)
+    r, o = F.Resampler(fi, fo, 3, bandwidth=bw), Oracle(fi, fo, 3, bandwidth=bw)
+    step = frames // 3 + 1
+    for lo in range(0, frames, step):
+        r.push(x[lo:lo + step]); o.push(x[lo:lo + step])
+        a, b = r.pull_all(), o.pull_all()
+        assert a.shape == b.shape, (lo, a.shape, b.shape)
+        if a.size:
+            assert_parity(a, b)
+    r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape
+    assert_parity(a, b)
+
+
+@pytest.mark.parametrize("fi,fo,bw", [(24000, 8000, 99.0), (16000, 8000, 99.7), (8000, 48000, 99.0)])
+def test_long_blocks_are_bit_invariant_to_push_size(fi, fo, bw):
+    """Long reference blocks are computed as the reference's blocks at absolute stream positions, so -- like the
+    reference -- the output bits do not depend on how the stream was pushed."""
+    x = lcg_noise(120000, 2, 47)
+    one = F.Resampler(fi, fo, 2, bandwidth=bw).process(x)
+    for chunk in (977, 30011):
+        y = F.Resampler(fi, fo, 2, bandwidth=bw).process(x, chunk=chunk)
+        assert y.shape == one.shape and np.array_equal(y, one), chunk
 
 
 def test_random_configurations_sweep():

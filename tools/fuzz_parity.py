@@ -29,7 +29,7 @@ def main(n_cases, seed):
         if rng.rand() < 0.3:
             kw["quality"] = 1
         if rng.rand() < 0.4:
-            kw["bandwidth"] = float(rng.choice([90.0, 97.0, 99.0]))
+            kw["bandwidth"] = float(rng.choice([90.0, 97.0, 99.0, 99.5]))
         if rng.rand() < 0.2:
             kw["allow_aliasing"] = 1
         frames = int(rng.randint(3000, 60000))
@@ -58,10 +58,7 @@ def main(n_cases, seed):
         rep = compare_f32(g, f)
         worst["max_ulp"] = max(worst["max_ulp"], rep["max_ulp"])
         worst["rel_rms"] = max(worst["rel_rms"], rep["rel_rms"])
-        # decoupled frequency-domain decimation (reference blocks of 32768) has the looser documented bar
-        # (Normal quality has a weaker stop band, so the block-length dependence of the truncation is larger: seen 2.6e-8)
-        loose_rms = 5e-8 if kw.get("quality") == 1 else 1e-8
-        ok = (rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7) or (rep["rel_rms"] <= loose_rms and rep["max_abs"] <= 2e-7)
+        ok = rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7  # one bar for every chain (tests/parity.py)
         if not ok:
             bad += 1
             print("MISMATCH case", k, fi, fo, nch, kw, frames, cuts, rep)
