@@ -717,6 +717,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.Vout = sp.step < 0 ? Ng - ((((1 << -sp.step) - 1) * Ng + ov) >> -sp.step) : Vg;
         a.q = (Vg - sp.remL0 + L - 1) / L;
         a.M = sp.step > 1 ? sp.step : 1;
+        a.hp = 0; // set by the launchers (frame_pairs)
         a.in_limit = 0x7fffffffffffffffLL;
         a.clip_lo = -0x7fffffffffffffffLL;
         a.clip_hi = 0x7fffffffffffffffLL;

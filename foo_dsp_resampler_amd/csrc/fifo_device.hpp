@@ -125,6 +125,45 @@ __device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool h
   return r;
 }
 
+// Work item -> (block, channel pair) for the one-workgroup-per-(block, pair) kernels; `lin` = linear workgroup id.
+//
+// hp <= 1 (stereo or planar data): pair-fastest order.  Blocks are dealt round-robin over the 8 XCDs, so with
+// npairs % 8 == 0 the consecutive blocks of one pair land on the same XCD and their input overlap is an L2 hit.
+//
+// hp >= 2 (interleaved float frames of 2*hp channels): the hp workgroups of one (block, stream) each touch 8 bytes of
+// every frame, i.e. the SAME 128-byte lines.  Spread over the 8 XCDs (each with its own L2) every line would be fetched
+// by several L2s and written back in pieces (measured on 8-channel frames: 4.6x the output bytes in WRITE_SIZE).  Here
+// they get linear ids lin, lin + 8, ..., lin + 8*(hp-1): same XCD under the observed round-robin placement, dispatched
+// together, so the pieces meet in one L2.  Placement is a speed matter only; any placement is correct.
+__device__ __forceinline__ bool item_map(int lin, int nblocks, int npairs, int hp, int &bl, int &pair)
+{
+  if (hp <= 1) {
+    bl = lin / npairs;
+    pair = lin - bl * npairs;
+    return bl < nblocks;
+  }
+  const int xcd = lin & 7, t = lin >> 3;
+  const int slot = t / hp, within = t - slot * hp, g = slot * 8 + xcd;
+  const int nstreams = npairs / hp;
+  if (g >= nblocks * nstreams) return false;
+  bl = g / nstreams;
+  pair = (g - bl * nstreams) * hp + within;
+  return true;
+}
+inline int item_grid(int nblocks, int npairs, int hp)
+{
+  if (hp <= 1) return nblocks * npairs;
+  const int ngroups = nblocks * (npairs / hp);
+  return (ngroups + 7) / 8 * 8 * hp;
+}
+// pairs per interleaved frame that share cache lines (0 when the grouping does not apply)
+inline int frame_pairs(const AnyView &in, const AnyView &out, int C)
+{
+  const AnyView *v = in.is_f32 ? &in : out.is_f32 ? &out : nullptr;
+  if (!v || (v->f.nch & 1) || v->f.nch < 4 || C % v->f.nch) return 0;
+  return v->f.nch / 2;
+}
+
 inline AnyView make_view(bool is_f32, const F32View &f, const F64View &d)
 {
   AnyView v;

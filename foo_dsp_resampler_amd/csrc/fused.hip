@@ -75,7 +75,6 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
 
   const int tid = threadIdx.x;
   const int npairs = (a.d.C + 1) >> 1;
-  const int nitems = a.d.nblocks * npairs;
   const int V = a.d.V;
   const bool fwd_active = tid < TF;
   const double2 *__restrict__ Gp = a.d.G;
@@ -95,9 +94,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   const double *__restrict__ cft = a.cft + tid;
 
   // RSMP_STAMPS instrumentation: wave 0's view of the phase boundaries (s_memtime, shader clock)
-  unsigned long long tstamp = a.stamps ? __builtin_readcyclecounter() : 0;
+  // (one workgroup in 64 is stamped, so that the stamps do not change what they measure)
+  const bool stamping = a.stamps && (blockIdx.x & 63) == 5;
+  unsigned long long tstamp = stamping ? __builtin_readcyclecounter() : 0;
 #define RSMP_STAMP(slot) \
-  if (a.stamps) { \
+  if (stamping) { \
     if (a.dbg & 256) __builtin_amdgcn_s_waitcnt(0); \
     const unsigned long long now = __builtin_readcyclecounter(); \
     if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp); \
@@ -105,9 +106,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   }
 
   { // one work item per workgroup (see the note above about a persistent loop)
-    const int w = blockIdx.x;
-    if (w >= nitems) return;
-    const int bl = w / npairs, pair = w - bl * npairs;
+    int bl, pair;
+    if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
     const long long B = a.d.B0 + bl;
     const int ca = 2 * pair, cb = ca + 1;
     const bool hasb = cb < a.d.C;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       }
     }
     RSMP_STAMP(5)
-    if (a.stamps && tid == 0) atomicAdd(a.stamps + 7, 1ull);
+    if (stamping && tid == 0) atomicAdd(a.stamps + 7, 1ull);
   }
 #undef RSMP_STAMP
 }
@@ -632,9 +632,10 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
       fprintf(stderr, "RSMP_OCC lds %zu blocks/CU %d (%s)\n", lds_bytes, nb, hipGetErrorString(eo));
     }
   }
-  const int nitems = a.d.nblocks * ((a.d.C + 1) / 2);
-  dim3 grid(nitems), block(N / 16);
-  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), grid, block, lds_bytes, st, in, out, a);
+  FusedArgs b = a;
+  b.d.hp = frame_pairs(in, out, a.d.C);
+  dim3 grid(item_grid(a.d.nblocks, (a.d.C + 1) / 2, b.d.hp)), block(N / 16);
+  hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), grid, block, lds_bytes, st, in, out, b);
   return hipGetLastError();
 }
 

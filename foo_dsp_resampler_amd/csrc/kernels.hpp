@@ -47,6 +47,7 @@ struct DftArgs {
   int Vout;              // outputs kept per block when M == 1 (V, or the frequency-domain decimated count)
   int q;                 // inputs consumed per block (frequency-domain paths)
   int M;                 // time-domain decimation step (1 = none)
+  int hp;                // channel pairs per interleaved float frame whose workgroups are co-located (item_map); 0/1 = none
   long long in_limit;    // input items at absolute index >= in_limit read as zero (unused by the engine: always +inf)
   long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored (always everything)
 };

@@ -31,7 +31,8 @@ class RRError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libratelib_amd.so")
+    # RATELIB_AMD_SO: another in-tree build of the same library (kernel experiments: tools/build_variant.sh)
+    return os.environ.get("RATELIB_AMD_SO") or os.path.join(HERE, "libratelib_amd.so")
 
 
 _lib = None
