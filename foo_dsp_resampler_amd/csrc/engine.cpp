@@ -8,6 +8,7 @@
 #include <atomic>
 #include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -159,8 +160,8 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   dbg_ = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
   no_side_ = getenv("RSMP_NO_SIDE") != nullptr;
   if (getenv("RSMP_STAMPS")) {
-    ALLOC_TRY(&stamps_, 8 * sizeof(unsigned long long));
-    HIP_TRY(hipMemset(stamps_, 0, 8 * sizeof(unsigned long long)));
+    ALLOC_TRY(&stamps_, 16 * sizeof(unsigned long long));
+    HIP_TRY(hipMemset(stamps_, 0, 16 * sizeof(unsigned long long)));
   }
   const int ns = int(plan_.stages.size());
   book_.wr.assign(ns + 1, 0);
@@ -317,6 +318,16 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         fu.NGRP = NGRP;
         fu.KS = KS;
         fu.qb_max = qb_max;
+        std::vector<int> qt(size_t(NGRP) * 4);
+        for (int g = 0; g < NGRP; ++g)
+          for (int bq = 0; bq < 4; ++bq) {
+            int rb = 16 * g + 4 * bq;
+            if (rb >= p.L) rb = 0; // idle block: all-zero coefficients, any in-range window will do
+            qt[size_t(g) * 4 + bq] = (at0 + rb * pstep) / p.L;
+          }
+        void *dq = nullptr;
+        if ((rc = upload(qt.data(), qt.size() * sizeof(int), &dq)) != kOk) return rc;
+        fu.qtab = static_cast<int *>(dq);
       }
     }
     const size_t per_launch = size_t(fu.blk_cap - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
@@ -504,8 +515,12 @@ Engine::~Engine()
   set_profiling(false);
   if (d_stage_) (void)hipFree(d_stage_);
   if (stamps_) {
-    unsigned long long h[8] = {};
-    if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7])
+    unsigned long long h[16] = {};
+    if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7] && h[9])
+      fprintf(stderr, "RSMP_FINE per workgroup (wave 0): setup %.0f  drain %.0f  flush %.0f  Aload+addr+fill %.0f  first-LDS %.0f  steps %.0f  bookkeeping %.0f  loop %.0f\n",
+              double(h[8]) / h[7], double(h[9]) / h[7], double(h[10]) / h[7], double(h[11]) / h[7], double(h[12]) / h[7], double(h[13]) / h[7],
+              double(h[14]) / h[7], double(h[15]) / h[7]);
+    if (h[7])
       fprintf(stderr, "RSMP_STAMPS workgroups %llu  avg cycles: load %.0f  fwd %.0f  mul %.0f  inv %.0f  cf+smp %.0f  polyA %.0f  poly(B) %.0f  total %.0f\n",
               h[7], double(h[0]) / h[7], double(h[1]) / h[7], double(h[2]) / h[7], double(h[3]) / h[7], double(h[4]) / h[7],
               double(h[6]) / h[7], double(h[5]) / h[7], double(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]) / h[7]);
@@ -515,6 +530,7 @@ Engine::~Engine()
     if (f.seam) (void)hipFree(f.seam);
     if (f.cft) (void)hipFree(f.cft);
     if (f.cfm) (void)hipFree(f.cfm);
+    if (f.qtab) (void)hipFree(f.qtab);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
   for (BigDft &b : big_) {
@@ -786,6 +802,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.KC = fu.KC;
           fa.kper = fu.kper;
           fa.cfm = fu.cfm;
+          fa.qtab = fu.qtab;
           fa.NGRP = fu.NGRP;
           fa.KS = fu.KS;
           fa.dbg = dbg_;
@@ -815,13 +832,54 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           const bool s32 = i - 1 == 0;
           if (seam_launches_ >= 2) // seam(k-2) read the slots this launch overwrites
             HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
-          const int pi = prof_begin(true);
-          const char *kn = nullptr;
-          HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
-                               s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                               dst_f32 ? nod : f64_view(i + 1), fa, stream_, &kn));
-          prof_name(pi, kn);
-          prof_end(pi);
+          // Blocks whose input span and outputs lie in the caller's buffers as plain interleaved frames go to the lean
+          // kernel (fused_fast.hip); the others (the block that straddles ring and buffer, ring wrap, odd channel counts,
+          // fp64 rings on either side) to the generic one.  At most three launches: generic head, lean middle, generic tail.
+          int f0 = 0, f1 = 0;
+          FastIo io = {};
+          if (fu.cfm && s32 && dst_f32 && !(nch_ & 1) && ein.ptr && eout.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
+              !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7) && !(ein.stride_floats & 1) &&
+              !(eout.stride_floats & 1)) {
+            const long long P = 1LL << pend_log2p, q = fa.d.q;
+            const long long lo = (ein.begin + q - 1) / q - pend.B0, hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
+            f0 = int(std::max<long long>(0, lo));
+            f1 = int(std::min<long long>(pend.nblocks, hi));
+            // outputs of blocks [f0, f1) must lie inside the caller's output buffer
+            while (f0 < f1) {
+              const FusedBlock b0 = fused_block_info(pa, f0), b1 = fused_block_info(pa, f1 - 1);
+              if (out_offset + b0.i_lo < eout.begin) { ++f0; continue; }
+              if (out_offset + b1.i_lo + b1.cnt > eout.end) { --f1; continue; }
+              break;
+            }
+            if (f0 >= f1) f0 = f1 = 0;
+            io.in = ein.ptr;
+            io.out = eout.ptr;
+            io.in_abs0 = ein.begin;
+            io.out_abs0 = eout.begin;
+            io.in_stream_stride = ein.stride_floats;
+            io.out_stream_stride = eout.stride_floats;
+            io.nch = nch_;
+          }
+          auto launch_range = [&](int b0, int b1, bool fast) -> int {
+            if (b0 >= b1) return kOk;
+            FusedArgs fr = fa;
+            fr.d.B0 = fa.d.B0 + b0;
+            fr.d.nblocks = b1 - b0;
+            fr.blk = fa.blk + b0;
+            const int pi = prof_begin(true);
+            const char *kn = nullptr;
+            if (fast) HIP_TRY(launch_fused_fast(pend_log2p, fr, io, stream_, &kn));
+            else
+              HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
+                                   s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                                   dst_f32 ? nod : f64_view(i + 1), fr, stream_, &kn));
+            prof_name(pi, kn);
+            prof_end(pi);
+            return kOk;
+          };
+          { int rl = launch_range(0, f0, false); if (rl) return rl; }
+          { int rl = launch_range(f0, f1, true); if (rl) return rl; }
+          { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
           // side stream only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
           if (profiling_ || !dst_f32 || no_side_) {
             const int ps = prof_begin(false, "rsmp::seam_kernel");

@@ -40,6 +40,11 @@
 #define RSMP_FWD8 0
 #endif
 // twiddles per pass prefetched ahead of the preceding LDS exchange (forward / inverse transform of the MF variant)
+// RSMP_FINE=1 (variant builds only): per-segment cycle sums of the polyphase item loop of wave 0 in the stamped workgroups,
+// with every counter drained at each segment boundary (slots 8..15 of the stamp buffer).
+#ifndef RSMP_FINE
+#define RSMP_FINE 0
+#endif
 #ifndef RSMP_PFW
 #define RSMP_PFW 15
 #endif
@@ -393,16 +398,32 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
         // the window start of outputs that are not stored anyway (block edges) into the image
         auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
           const int ncs = (ke - kb + 3) >> 2, half0 = (ncs + 1) >> 1; // column steps of 4 periods
+#if RSMP_FINE
+#define RSMP_TICK(slot, drain)                                         \
+  if (stamping) {                                                       \
+    if (drain) __builtin_amdgcn_s_waitcnt(0);                           \
+    const unsigned long long now = __builtin_readcyclecounter();       \
+    if (tid == 0) atomicAdd(a.stamps + (slot), now - ftick);            \
+    ftick = __builtin_readcyclecounter();                               \
+  }
+          unsigned long long ftick = stamping ? __builtin_readcyclecounter() : 0;
+#else
+#define RSMP_TICK(slot, drain)
+#endif
           for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
+            RSMP_TICK(15, 0)
             const int g = it >> 1, second = (it + (it >> 2)) & 1; // halves alternate so the waves stay balanced
             int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
             // column steps whose 64 outputs all lie outside [irel_lo, irel_hi) (block edges) are skipped
             while (cs0 < cs1 && (kb + 4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
             while (cs1 > cs0 && (kb + 4 * (cs1 - 1)) * pl + 16 * g >= irel_hi) --cs1;
+            RSMP_TICK(8, 0)   // item set-up (skip tests)
+            RSMP_TICK(9, 1)   // everything still in flight from the previous item: A tile loads, stores, LDS reads
             double ca_[SPAN];
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
             flush();
+            RSMP_TICK(10, 0)  // conversions + store issue
             if (!(a.dbg & 1024)) {
               const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
               const double *cp = a.cfm + (nx >> 1) * (SPAN * 64);    // uniform base, lane offset added by the load
@@ -434,6 +455,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
               }
             };
             if (cs0 < cs1) fill(x0, cs0);
+            RSMP_TICK(11, 0)  // A tile load issue, window address (integer division), first fill issue
+#if RSMP_FINE
+            if (stamping) { __builtin_amdgcn_s_waitcnt(0xc07f); } // lgkmcnt(0) only
+#endif
+            RSMP_TICK(12, 0)  // first fill's LDS round trip
 #pragma unroll
             for (int u = 0; u < MAXCS; ++u) {
               if (cs0 + u < cs1) {
@@ -441,6 +467,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
                 column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
               }
             }
+            RSMP_TICK(13, 0)  // column steps
             // bookkeeping for the deferred stores
             const int rD = 16 * g + 4 * bq + hi, k0 = kb + 4 * cs0;
             pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
@@ -454,6 +481,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
                 if (k0 + 4 * u + 3 < ke && (k0 + 4 * u) * pl + 16 * g >= fb.irel_lo && (k0 + 4 * u + 3) * pl + 16 * g + 15 < irel_hi)
                   pend_allv |= 1 << u;
             }
+            RSMP_TICK(14, 0)  // store bookkeeping
           }
         };
         // round A: periods whose windows end inside the samples written above

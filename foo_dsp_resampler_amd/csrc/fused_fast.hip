@@ -1,0 +1,278 @@
+// Lean form of the headline kernel: dft(xL, L in {1,2}, N = 4096) -> vpoly0 on the fp64 matrix pipe, for the blocks whose
+// input and output are plain interleaved float frames in one buffer each (what a device-resident push / flow of whole
+// blocks looks like; rate/dft_filter.h:60-190 followed by rate/rate_filters_generic.h:272-305).
+//
+// Same mathematics, same summation order and the same two-round LDS sample image as fused_kernel<.., true> (fused.hip);
+// what differs is the bookkeeping around it:
+//   * no generic fifo addressing: the host hands over one base pointer per side (FastIo) and launches this kernel only
+//     for block ranges it has checked (fused_fast_range); other blocks go to fused_kernel;
+//   * the polyphase stage walks TILES (16 output residues x 4 periods = one accumulator pair) in group-major order, each
+//     wave a contiguous range of them: the coefficient tile changes only when the residue group does (double-buffered,
+//     prefetched a group ahead), the window start of a group comes from a host table instead of an integer division
+//     per lane, every store is issued straight after its tile under a per-lane range test (no deferred-store state,
+//     no per-step validity masks, no skip loops);
+//   * the next tile's samples are always prefetched (clamped address), so the wait before a tile's MFMA chain is for
+//     reads issued one whole tile earlier.
+// The old kernel spent ~1200 integer / 1650 scalar instructions per wave and had 1000+ SGPR spill moves in its code;
+// this one keeps the scalar state of the tile loop in a dozen registers.
+#include "fft_device.hpp"
+#include "fifo_device.hpp"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstdio>
+
+#ifndef RSMP_PFW
+#define RSMP_PFW 15
+#endif
+#ifndef RSMP_PFI
+#define RSMP_PFI 8
+#endif
+
+namespace rsmp {
+
+namespace {
+constexpr int kPad = 32;
+constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
+} // namespace
+
+template <int LOG2P, int KS>
+__global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
+{
+  constexpr int LOG2N = 12, N = 1 << LOG2N, P = 1 << LOG2P;
+  constexpr int T = N / 16, TF = P / 16;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int tid = threadIdx.x;
+  const int npairs = a.d.C >> 1; // even channel count (host-checked)
+  int bl, pair;
+  if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
+  const long long B = a.d.B0 + bl;
+  const int hp = io.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+  const int V = a.d.V;
+  const bool fwd_active = tid < TF;
+  const double2 *__restrict__ Gp = a.d.G;
+  double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
+  const int nm1 = a.n - 1;
+
+  // ---------------------------------------------------------------- load the block (fp32 -> fp64)
+  c64 v[16];
+  {
+    const float2 *p2 = reinterpret_cast<const float2 *>(io.in + strm * io.in_stream_stride + (B * a.d.q - io.in_abs0) * io.nch + 2 * pin);
+    if (fwd_active) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float2 f = p2[(tid + s * TF) * hp];
+        v[s] = {(double)f.x, (double)f.y};
+      }
+    }
+  }
+  // ---------------------------------------------------------------- FFT-FIR (as fused_kernel)
+  fft_regs<LOG2P, -1, LOG2P == LOG2N ? 2 : 0, RSMP_PFW>(v, tid, fwd_active, a.d.tw_fwd, lds);
+  if constexpr (LOG2P < LOG2N) {
+    double2 g[16]; // issued before the exchange so the L2 latency overlaps it
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    // Z[tid + s*T] = Zp[tid + (s & 7) * T]: a forward thread (tid < TF) already holds those in its even slots; its odd
+    // slots are what thread tid + TF needs
+    if (fwd_active) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) l2[tid + u * TF] = make_double2(v[2 * u + 1].x, v[2 * u + 1].y);
+    }
+    __syncthreads();
+    c64 z[8];
+    if (fwd_active) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = v[2 * u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double2 q = l2[tid - TF + u * TF];
+        z[u] = {q.x, q.y};
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = cmul(z[s & 7], c64{g[s].x, g[s].y});
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double2 g = Gp[tid + s * T];
+      v[s] = cmul(v[s], c64{g.x, g.y});
+    }
+  }
+  fft_regs<LOG2N, +1, 2, RSMP_PFI>(v, tid, true, a.d.tw_inv, lds);
+
+  // ---------------------------------------------------------------- stage-1 samples -> LDS (round A) and seam ring
+  const int ca = 2 * pair, cb = ca + 1;
+  {
+    const int slot = (int)(B & a.seam_mask);
+    double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
+    double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int n = tid + s * T;
+      if (n < V) {
+        if (s < kSA || (s == kSA && tid < kPad)) smp[n] = make_double2(v[s].x, v[s].y);
+        if (n < nm1) {
+          seamA[n] = v[s].x;
+          seamB[n] = v[s].y;
+        }
+        if (n >= V - nm1) {
+          seamA[32 + n - (V - nm1)] = v[s].x;
+          seamB[32 + n - (V - nm1)] = v[s].y;
+        }
+      }
+    }
+    if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
+      smp[tid - kPad] = make_double2(0.0, 0.0);
+      if (V < kSA * T + kPad) smp[V + tid] = make_double2(0.0, 0.0);
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- polyphase FIR on v_mfma_f64_4x4x4, tile by tile
+  // Lane maps (tools/probe_mfma4.hip): A lane = 16k + 4b + i, B lane = 16k + 4b + j, D lane = 16i + 4b + j:
+  // as an A/B lane this lane is (k = hi, block bq, i or j = jq); its D element is (row hi, block bq, period jq).
+  const FusedBlock fb = a.blk[bl];
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+  const int pl = a.polyL, step = a.step;
+  const int irel_hi = fb.irel_lo + fb.cnt;
+  const int frame_bytes = io.nch * 4;
+  char *const obytes = reinterpret_cast<char *>(io.out + strm * io.out_stream_stride + (a.out_offset2 + fb.i_lo - io.out_abs0) * io.nch + 2 * pin);
+  const int rloc = 4 * bq + hi; // this lane's output residue within a 16-residue group
+  const int ngrp = a.NGRP;
+  const double *const cfm_lane = a.cfm + lane;
+  const int *const qtab_lane = a.qtab + bq;
+
+  auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
+    const int ncs = (ke - kb + 3) >> 2; // column steps (4 periods each) of this round
+    const int nt = ngrp * ncs;
+    const int t0 = (nt * wave) >> 2, t1 = (nt * (wave + 1)) >> 2; // this wave's tiles, group-major
+    if (t0 >= t1) return;
+    int g = t0 / ncs, c = t0 - g * ncs;
+    const int g_last = (t1 - 1) / ncs;
+    const int hi_bound = min(irel_hi, ke * pl);
+    const int lane_li = fb.base_li + hi + (kb + jq) * step; // window start = lane_li + q(group, block) + c * 4 * step
+    const int lane_ib = (kb + jq) * pl + rloc - fb.irel_lo; // output index relative to i_lo = lane_ib + 16 g + c * 4 * pl
+    const int cnt = hi_bound - fb.irel_lo;
+    const int step4 = 4 * step, pl4 = 4 * pl;
+
+    double cc[KS], cn[KS]; // coefficient tiles: current group, next group (in flight)
+    int qc, qn = 0;
+    auto load_tile = [&](int gg, double (&c_)[KS], int &q_) {
+      const double *cp = cfm_lane + gg * (KS * 64); // uniform offset
+#pragma unroll
+      for (int s = 0; s < KS; ++s) c_[s] = cp[s * 64];
+      q_ = qtab_lane[gg * 4];
+    };
+    load_tile(g, cc, qc);
+    if (g < g_last) load_tile(g + 1, cn, qn);
+
+    double2 x0[KS], x1[KS];
+    auto fill = [&](double2 (&x)[KS], int q, int cstep) {
+      const int li = max(li_lo, min(li_hi, lane_li + q + cstep * step4));
+      const double2 *xp = xs + li;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x[s] = xp[4 * s];
+    };
+    fill(x0, qc, c);
+
+    int left = t1 - t0;
+    // one tile: prefetch the next tile's samples into `xn`, run the two accumulation chains on `xc`, store
+    auto tile = [&](const double2 (&xc)[KS], double2 (&xn)[KS]) {
+      int cnext = c + 1, gnext = g;
+      if (cnext == ncs) {
+        cnext = 0;
+        gnext = g + 1;
+      }
+      const bool switch_group = gnext != g && left > 1;
+      fill(xn, switch_group ? qn : qc, left > 1 ? cnext : c); // after the last tile: a harmless re-read
+      double accA = 0.0, accB = 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        accA = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].x, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].y, accB, 0, 0, 0);
+      }
+      const int ib = lane_ib + 16 * g + c * pl4;
+      if (ib >= 0 && ib < cnt && 16 * g + rloc < pl)
+        *reinterpret_cast<float2 *>(obytes + (unsigned)(ib * frame_bytes)) = make_float2((float)accA, (float)accB);
+      if (switch_group) { // uniform
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cc[s] = cn[s];
+        qc = qn;
+        if (gnext < g_last) load_tile(gnext + 1, cn, qn);
+      }
+      g = gnext;
+      c = cnext;
+      --left;
+    };
+    while (true) {
+      tile(x0, x1);
+      if (left == 0) break;
+      tile(x1, x0);
+      if (left == 0) break;
+    }
+  };
+
+  const bool run = fb.cnt > 0;
+  // round A: periods whose windows end inside the samples written above
+  if (run) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * KS);
+  __syncthreads();
+  // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
+  {
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+    for (int s = kSB0; s < 16; ++s) {
+      const int n = tid + s * T;
+      if (n < V) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
+    }
+    if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  if (run && fb.KA < fb.K) poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * KS);
+}
+
+template <int LOG2P, int KS> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
+{
+  constexpr int N = 4096;
+  size_t lds_bytes = 8 * size_t(fft_lds_doubles_halves(12));
+  if (LOG2P < 12) lds_bytes = std::max(lds_bytes, 8 * size_t(fft_lds_doubles(LOG2P)));
+  lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_fast_kernel<LOG2P, KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+    if (e != hipSuccess) return e;
+    attr_done.store(true, std::memory_order_release);
+  }
+  FusedArgs b = a;
+  b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
+  dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(N / 16);
+  hipLaunchKernelGGL((fused_fast_kernel<LOG2P, KS>), grid, block, lds_bytes, st, b, io);
+  return hipGetLastError();
+}
+
+bool fused_fast_supported(int log2n, int log2p, int ksteps)
+{
+  static const bool off = getenv("RSMP_NO_FAST") != nullptr;
+  return !off && log2n == 12 && (log2p == 11 || log2p == 12) && (ksteps == 7 || ksteps == 8);
+}
+
+#define RSMP_FAST_CASE(p, ks)                                                  \
+  if (log2p == p && a.KS == ks) {                                              \
+    if (kname) *kname = "rsmp::fused_fast_kernel<" #p ", " #ks ">";            \
+    return launch_fast_t<p, ks>(a, io, st);                                    \
+  }
+
+hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
+{
+  RSMP_FAST_CASE(11, 7) RSMP_FAST_CASE(12, 7) RSMP_FAST_CASE(11, 8) RSMP_FAST_CASE(12, 8)
+  return hipErrorInvalidValue;
+}
+
+} // namespace rsmp

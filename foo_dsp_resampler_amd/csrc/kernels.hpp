@@ -133,7 +133,19 @@ struct FusedArgs {
   int dbg;               // profiling ablations (RSMP_DBG env); 0 in production
   unsigned long long *stamps; // RSMP_STAMPS: per-phase cycle sums [8] (null in production)
   const FusedBlock *blk; // [nblocks] in HBM, written by fused_prep_kernel ahead of the launch
+  const int *qtab;       // matrix-pipe variant: window start (at0 + rb*step)/polyL of every 4-residue block rb = 4*i, [NGRP*4]
 };
+
+// Lean fast path of the matrix-pipe variant (fused_fast.hip): both ends are plain interleaved float frames in one buffer each
+struct FastIo {
+  const float *in;            // frame `in_abs0` (absolute input index) of stream 0, channel 0
+  float *out;                 // frame `out_abs0` (absolute index in the output fifo) of stream 0, channel 0
+  long long in_abs0, out_abs0;
+  long long in_stream_stride, out_stream_stride; // floats between streams
+  int nch;                    // channels per stream (even)
+};
+bool fused_fast_supported(int log2n, int log2p, int ksteps);
+hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
 
 struct PolyArgs {
   const double *tab;     // [phase][tap][order+1]
