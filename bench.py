@@ -175,13 +175,15 @@ def main():
         S = cfg["streams"]
     r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
     P = min(args.frames or cfg.get("frames") or r.isamp_max, r.isamp_max)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)
-
     g = torch.Generator(device="cuda").manual_seed(12345 + rank)
     x = torch.rand((S, P, nch), generator=g, device="cuda", dtype=torch.float32) - 0.5
     cap = int(P * fo / fi) + 8192
     y = torch.empty((S, cap, nch), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    # the engine runs on a stream of ours (a NULL handle would mean "the handle's own stream", include/ratelib_amd.h), so
+    # the HIP events below bracket exactly the work of the timed steps
+    stream = torch.cuda.Stream()
+    r.set_stream(stream.cuda_stream)
 
     def step():
         iu, og = r.flow_device(x, P, y, cap)

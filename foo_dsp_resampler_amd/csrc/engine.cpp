@@ -298,7 +298,11 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       int qb_min = at0 / p.L, qb_max = qb_min;
       for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
       // ... and at most 32 periods per block (4 column steps per item), enough phases to fill 16-row tiles
-      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= 256 + 32 && Kmax <= 32 && p.L >= 64;
+      // ... and the zero padding must stay small: taps are padded to 4*KS, phases to 16*NGRP.  Measured: 44.1k->48k (24 of 32
+      // taps, 80 of 80 rows = 75 % useful) 3.48 ms against 4.87 ms for the vector variant; 96k->44.1k (24 of 32 taps and 147 of
+      // 160 rows = 69 %) 3.90 ms against 3.74 ms, so that chain stays on the vector variant.
+      const bool dense = double(p.n) * p.L >= 0.72 * (4.0 * KS) * (16.0 * NGRP);
+      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && dense;
       if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)
@@ -318,6 +322,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         fu.NGRP = NGRP;
         fu.KS = KS;
         fu.qb_max = qb_max;
+        fu.qb_min = qb_min;
         std::vector<int> qt(size_t(NGRP) * 4);
         for (int g = 0; g < NGRP; ++g)
           for (int bq = 0; bq < 4; ++bq) {
@@ -496,6 +501,32 @@ int Engine::join_side()
   return kOk;
 }
 
+int Engine::pinned_reserve(Pinned &b, size_t floats)
+{
+  if (!b.done) HIP_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  if (b.floats >= floats) return kOk;
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.floats = 0;
+  size_t want = 4096;
+  while (want < floats) want <<= 1;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, want * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return kNoMem;
+  }
+  b.p = static_cast<float *>(p);
+  b.floats = want;
+  return kOk;
+}
+
+void Engine::pinned_free(Pinned &b)
+{
+  if (b.p) (void)hipHostFree(b.p);
+  if (b.done) (void)hipEventDestroy(b.done);
+  b = Pinned();
+}
+
 void Engine::free_garbage()
 {
   for (void *p : garbage_) (void)hipFree(p);
@@ -514,6 +545,9 @@ Engine::~Engine()
   for (double2 *&t : d_tw8_) if (t) (void)hipFree(t);
   set_profiling(false);
   if (d_stage_) (void)hipFree(d_stage_);
+  pinned_free(pin_in_[0]);
+  pinned_free(pin_in_[1]);
+  pinned_free(pin_out_);
   if (stamps_) {
     unsigned long long h[16] = {};
     if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7] && h[9])
@@ -820,6 +854,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.two_round = fu.cfm != nullptr;
           pa.KS = fu.KS;
           pa.qb_max = fu.qb_max;
+          pa.qb_min = fu.qb_min;
           pa.clip_lo = 0;
           pa.clip_hi = 0x7fffffffffffffffLL;
           for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
@@ -841,8 +876,9 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
               !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7) && !(ein.stride_floats & 1) &&
               !(eout.stride_floats & 1)) {
             const long long P = 1LL << pend_log2p, q = fa.d.q;
-            const long long lo = (ein.begin + q - 1) / q - pend.B0, hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
-            f0 = int(std::max<long long>(0, lo));
+            // (a block that starts below the caller's buffer takes its head from fifo 0's ring: the lean kernel handles that too)
+            const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
+            f0 = 0;
             f1 = int(std::min<long long>(pend.nblocks, hi));
             // outputs of blocks [f0, f1) must lie inside the caller's output buffer
             while (f0 < f1) {
@@ -853,6 +889,9 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
             }
             if (f0 >= f1) f0 = f1 = 0;
             io.in = ein.ptr;
+            io.in_ring = static_cast<const float *>(rings_[0].buf);
+            io.in_ring_mask = rings_[0].cap - 1;
+            io.in_ring_stream_stride = rings_[0].cap * nch_;
             io.out = eout.ptr;
             io.in_abs0 = ein.begin;
             io.out_abs0 = eout.begin;
@@ -913,6 +952,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.two_round = 0;
           pa.KS = pm.KS;
           pa.qb_max = 0;
+          pa.qb_min = 0;
           pa.clip_lo = i_begin;
           pa.clip_hi = i_end;
           for (int k : {0, pa.nblocks - 1})
@@ -1090,7 +1130,19 @@ int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
     stage_floats_ = need;
   }
   const size_t row = isamp * nch_ * sizeof(float);
-  if (S_ == 1) HIP_TRY(hipMemcpyAsync(d_stage_, ibuf, row, hipMemcpyHostToDevice, stream_));
+  if (need * sizeof(float) <= kPinnedMaxBytes) {
+    Pinned &slot = pin_in_[pin_k_ ^= 1];
+    if (slot.pending) { // the copy that last used this slot (two pushes ago) must have left it
+      HIP_TRY(hipEventSynchronize(slot.done));
+      slot.pending = false;
+    }
+    int rp = pinned_reserve(slot, need);
+    if (rp) return rp;
+    for (int s = 0; s < S_; ++s) std::memcpy(slot.p + size_t(s) * isamp * nch_, ibuf + size_t(s) * stream_stride * nch_, row);
+    HIP_TRY(hipMemcpyAsync(d_stage_, slot.p, need * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipEventRecord(slot.done, stream_));
+    slot.pending = true;
+  } else if (S_ == 1) HIP_TRY(hipMemcpyAsync(d_stage_, ibuf, row, hipMemcpyHostToDevice, stream_));
   else HIP_TRY(hipMemcpy2DAsync(d_stage_, row, ibuf, stream_stride * nch_ * sizeof(float), row, S_, hipMemcpyHostToDevice, stream_));
   return feed(d_stage_, isamp, isamp, nullptr, 0, 0, nullptr);
 }
@@ -1102,17 +1154,27 @@ int Engine::copy_out(float *dst, size_t stride_frames, size_t frames, bool to_ho
   const Ring &r = rings_[f];
   const long long rd = book_.rd[f];
   if (to_host) {
+    const size_t total = frames * size_t(nch_) * size_t(S_) * sizeof(float);
+    const bool pinned = total <= kPinnedMaxBytes;
+    if (pinned) {
+      int rp = pinned_reserve(pin_out_, total / sizeof(float));
+      if (rp) return rp;
+    }
     size_t done = 0;
     while (done < frames) { // at most two segments (ring wrap)
       const long long pos = (rd + (long long)done) & (r.cap - 1);
       const size_t n = std::min<size_t>(frames - done, size_t(r.cap - pos));
       const size_t row = n * nch_ * sizeof(float);
       const float *src = static_cast<const float *>(r.buf) + pos * nch_;
-      HIP_TRY(hipMemcpy2DAsync(dst + done * nch_, stride_frames * nch_ * sizeof(float), src, size_t(r.cap) * nch_ * sizeof(float),
-                               row, S_, hipMemcpyDeviceToHost, stream_));
+      float *d = pinned ? pin_out_.p + done * nch_ : dst + done * nch_;
+      const size_t dpitch = (pinned ? frames : stride_frames) * nch_ * sizeof(float);
+      HIP_TRY(hipMemcpy2DAsync(d, dpitch, src, size_t(r.cap) * nch_ * sizeof(float), row, S_, hipMemcpyDeviceToHost, stream_));
       done += n;
     }
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (pinned)
+      for (int s = 0; s < S_; ++s)
+        std::memcpy(dst + size_t(s) * stride_frames * nch_, pin_out_.p + size_t(s) * frames * nch_, frames * nch_ * sizeof(float));
     free_garbage(); // everything queued before this point has finished: retired rings / drain buffers can go
   } else {
     ExtOut eo;

@@ -125,7 +125,7 @@ private:
   std::vector<BigDft> big_;         // indexed by stage
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0;
-                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0; int *qtab = nullptr;
+                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0, qb_min = 0; int *qtab = nullptr;
                 FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   // standalone matrix-pipe polyphase stage (polymf.hip), indexed by the poly stage
@@ -143,6 +143,16 @@ private:
   unsigned long long *stamps_ = nullptr; // RSMP_STAMPS: device buffer of per-phase cycle sums
   float *d_stage_ = nullptr;
   size_t stage_floats_ = 0;
+  // Pinned host staging for RR_push / RR_pull (the plugin's 1-8 k-frame chunks): the caller's pageable buffer is copied
+  // into page-locked memory on the CPU, so the H2D copy is a true asynchronous DMA and a push returns without waiting for
+  // the device; two input slots alternate, each guarded by an event recorded behind its copy.  Pushes larger than
+  // kPinnedMaxBytes keep the direct (runtime-staged) path.
+  struct Pinned { float *p = nullptr; size_t floats = 0; hipEvent_t done = nullptr; bool pending = false; };
+  Pinned pin_in_[2], pin_out_;
+  int pin_k_ = 0;
+  static constexpr size_t kPinnedMaxBytes = size_t(64) << 20;
+  int pinned_reserve(Pinned &b, size_t floats);
+  void pinned_free(Pinned &b);
   size_t slab_frames_ = 0;
 };
 

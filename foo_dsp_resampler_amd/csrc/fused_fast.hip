@@ -24,6 +24,9 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef RSMP_FAST_FWD8
+#define RSMP_FAST_FWD8 1
+#endif
 #ifndef RSMP_PFW
 #define RSMP_PFW 15
 #endif
@@ -57,20 +60,60 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
   const int nm1 = a.n - 1;
 
+  // RSMP_STAMPS=1: per-phase cycle sums of wave 0 (s_memtime) in one workgroup of 64, printed when the handle closes
+  const bool stamping = a.stamps && (blockIdx.x & 63) == 5;
+  unsigned long long tstamp = stamping ? __builtin_readcyclecounter() : 0;
+#define RSMP_STAMP(slot)                                          \
+  if (stamping) {                                                  \
+    const unsigned long long now = __builtin_readcyclecounter();  \
+    if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp);      \
+    tstamp = now;                                                  \
+  }
+
   // ---------------------------------------------------------------- load the block (fp32 -> fp64)
+  // L = 2 (FWD8): the forward transform has half the points of the inverse one and runs 8 points per thread on ALL
+  // waves (fft8_regs); a thread then already holds the 8 distinct spectrum values Zp[tid + (s & 7) * T] its 16
+  // inverse-transform inputs need, so the replication exchange disappears.
+  constexpr bool FWD8 = (LOG2P == LOG2N - 1) && RSMP_FAST_FWD8;
+  constexpr int NLD = FWD8 ? 8 : 16, TL = FWD8 ? T : TF; // points per loading thread, loading threads
   c64 v[16];
+  c64 u8[8];
   {
-    const float2 *p2 = reinterpret_cast<const float2 *>(io.in + strm * io.in_stream_stride + (B * a.d.q - io.in_abs0) * io.nch + 2 * pin);
-    if (fwd_active) {
+    const long long e0 = B * a.d.q;
+    const bool ld_active = FWD8 || fwd_active;
+    if (e0 >= io.in_abs0) { // uniform: the whole block lies in the caller's buffer
+      const float2 *p2 = reinterpret_cast<const float2 *>(io.in + strm * io.in_stream_stride + (e0 - io.in_abs0) * io.nch + 2 * pin);
+      if (ld_active) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float2 f = p2[(tid + s * TF) * hp];
-        v[s] = {(double)f.x, (double)f.y};
+        for (int s = 0; s < NLD; ++s) {
+          const float2 f = p2[(tid + s * TL) * hp];
+          (FWD8 ? u8[s & 7] : v[s]) = {(double)f.x, (double)f.y};
+        }
+      }
+    } else if (ld_active) { // first block of a push: its head is the previous push's tail, kept in fifo 0's ring
+      const float *pe = io.in + strm * io.in_stream_stride + 2 * pin, *pr = io.in_ring + strm * io.in_ring_stream_stride + 2 * pin;
+#pragma unroll
+      for (int s = 0; s < NLD; ++s) {
+        const long long e = e0 + tid + s * TL;
+        const float2 f = *reinterpret_cast<const float2 *>(e >= io.in_abs0 ? pe + (e - io.in_abs0) * io.nch : pr + (e & io.in_ring_mask) * io.nch);
+        (FWD8 ? u8[s & 7] : v[s]) = {(double)f.x, (double)f.y};
       }
     }
   }
+  RSMP_STAMP(0)
   // ---------------------------------------------------------------- FFT-FIR (as fused_kernel)
+  if constexpr (FWD8) {
+    double2 g[16]; // in flight during the whole forward transform
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
+    fft8_regs<LOG2P, -1>(u8, tid, a.d.tw_fwd8, lds);
+    RSMP_STAMP(1)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = cmul(u8[s & 7], c64{g[s].x, g[s].y});
+    __syncthreads(); // the inverse transform's exchange reuses the LDS the forward one just read
+  } else {
   fft_regs<LOG2P, -1, LOG2P == LOG2N ? 2 : 0, RSMP_PFW>(v, tid, fwd_active, a.d.tw_fwd, lds);
+  RSMP_STAMP(1)
   if constexpr (LOG2P < LOG2N) {
     double2 g[16]; // issued before the exchange so the L2 latency overlaps it
 #pragma unroll
@@ -104,7 +147,10 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       v[s] = cmul(v[s], c64{g.x, g.y});
     }
   }
+  }
+  RSMP_STAMP(2)
   fft_regs<LOG2N, +1, 2, RSMP_PFI>(v, tid, true, a.d.tw_inv, lds);
+  RSMP_STAMP(3)
 
   // ---------------------------------------------------------------- stage-1 samples -> LDS (round A) and seam ring
   const int ca = 2 * pair, cb = ca + 1;
@@ -133,6 +179,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     }
   }
   __syncthreads();
+  RSMP_STAMP(4)
 
   // ---------------------------------------------------------------- polyphase FIR on v_mfma_f64_4x4x4, tile by tile
   // Lane maps (tools/probe_mfma4.hip): A lane = 16k + 4b + i, B lane = 16k + 4b + j, D lane = 16i + 4b + j:
@@ -222,6 +269,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   const bool run = fb.cnt > 0;
   // round A: periods whose windows end inside the samples written above
   if (run) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * KS);
+  RSMP_STAMP(6)
   __syncthreads();
   // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
   {
@@ -235,13 +283,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   }
   __syncthreads();
   if (run && fb.KA < fb.K) poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * KS);
+  RSMP_STAMP(5)
+  if (stamping && tid == 0) atomicAdd(a.stamps + 7, 1ull);
+#undef RSMP_STAMP
 }
 
 template <int LOG2P, int KS> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
   constexpr int N = 4096;
   size_t lds_bytes = 8 * size_t(fft_lds_doubles_halves(12));
-  if (LOG2P < 12) lds_bytes = std::max(lds_bytes, 8 * size_t(fft_lds_doubles(LOG2P)));
+  if (LOG2P < 12) lds_bytes = std::max(lds_bytes, 8 * size_t(std::max(fft_lds_doubles(LOG2P), fft8_lds_doubles(LOG2P))));
   lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
   static std::atomic<bool> attr_done{false};
   if (!attr_done.load(std::memory_order_acquire)) {

@@ -76,11 +76,12 @@ struct FusedBlock {
 };
 // Matrix-pipe variant of the fused kernel (N = 4096, 256 threads): the block's samples sit in LDS in two rounds,
 // round A = register slots [0, kFusedSA) of the inverse FFT (samples [0, 256*kFusedSA) plus a 32-sample margin),
-// round B = slots [kFusedSB0, 16).  RSMP_WG4 sizes them for four workgroups per CU instead of three.
+// round B = slots [kFusedSB0, 16); the two overlap by (kFusedSA - kFusedSB0) * 256 + 32 samples, which every period's
+// windows (all residues) must fit into one way or the other.  RSMP_WG4 sizes them for four workgroups per CU instead of three.
 #ifndef RSMP_WG4
 #define RSMP_WG4 0
 #endif
-constexpr int kFusedSA = RSMP_WG4 ? 9 : 12, kFusedSB0 = kFusedSA - 1, kFusedWaves = RSMP_WG4 ? 4 : 3;
+constexpr int kFusedSA = RSMP_WG4 ? 9 : 12, kFusedSB0 = kFusedSA - 2, kFusedWaves = RSMP_WG4 ? 4 : 3;
 
 // Closed forms of a block's bookkeeping; evaluated by fused_prep_kernel on the device (one thread per block of the
 // launch) and by the engine for its consistency checks.
@@ -88,6 +89,7 @@ struct FusedPrepArgs {
   long long b_offset, B0, at0; // as in FusedArgs / DftArgs
   int V, polyL, step, n, nblocks;
   int two_round, KS, qb_max;   // matrix-pipe variant: split of the periods over its two LDS images
+  int qb_min;                  // (smallest / largest window start of a 4-residue block, relative to its period)
   long long clip_lo, clip_hi;  // only outputs with index in [clip_lo, clip_hi) belong to this launch (standalone stage)
 };
 __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, int k)
@@ -109,6 +111,10 @@ __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, i
     const int a_hi = kFusedSA * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
     const int ka = num < 0 ? 0 : num / p.step + 1;
     fb.KA = ka < fb.K ? ka : fb.K;
+    // a multiple of 4 periods in the first image when the second one can take the rest: the two rounds then need
+    // ceil(K / 4) column steps of 4 periods together instead of one more
+    const int k4 = fb.KA & ~3;
+    if (fb.KA < fb.K && k4 > 0 && fb.base_li + p.qb_min + k4 * p.step >= kFusedSB0 * 256) fb.KA = k4;
   }
   return fb;
 }
@@ -139,6 +145,8 @@ struct FusedArgs {
 // Lean fast path of the matrix-pipe variant (fused_fast.hip): both ends are plain interleaved float frames in one buffer each
 struct FastIo {
   const float *in;            // frame `in_abs0` (absolute input index) of stream 0, channel 0
+  const float *in_ring;       // frames below in_abs0 (the tail of the previous push): fifo 0's ring, frame (index & in_ring_mask)
+  long long in_ring_mask, in_ring_stream_stride;
   float *out;                 // frame `out_abs0` (absolute index in the output fifo) of stream 0, channel 0
   long long in_abs0, out_abs0;
   long long in_stream_stride, out_stream_stride; // floats between streams

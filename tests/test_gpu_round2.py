@@ -28,7 +28,7 @@ def test_cfg4_per_gpu_shard_against_oracle():
     nch, fi, fo, n = 2, 44100, 48000, 60000
     x = torch.stack([torch.from_numpy(lcg_noise(n, nch, 12345 + first + s)) for s in range(S)]).cuda()
     r = F.Resampler(fi, fo, nch=nch, nstreams=S)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
     cap = int(n * fo / fi) + 4096
     y = torch.zeros((S, cap, nch), device="cuda")
     got = 0

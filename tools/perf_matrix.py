@@ -26,11 +26,12 @@ CASES = [
 def run(name, fi, fo, nch, S, kw, steps=5, frames=200000):
     r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
     P = min(frames, r.isamp_max)
-    st = torch.cuda.current_stream()
-    r.set_stream(st.cuda_stream)
+    st = torch.cuda.Stream()
     x = torch.rand((S, P, nch), device="cuda") - 0.5
     cap = int(P * fo / fi) + 65536
     y = torch.empty((S, cap, nch), device="cuda")
+    torch.cuda.synchronize()
+    r.set_stream(st.cuda_stream)
     for _ in range(2):
         r.flow_device(x, P, y, cap)
     torch.cuda.synchronize()
