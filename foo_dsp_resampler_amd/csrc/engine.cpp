@@ -377,6 +377,18 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     void *dm = nullptr;
     if ((rc = upload(am.data(), am.size() * sizeof(double), &dm)) != kOk) return rc;
     pm.cfm = static_cast<double *>(dm);
+    {
+      std::vector<int> qt(size_t(NGRP) * 4);
+      for (int g = 0; g < NGRP; ++g)
+        for (int bq = 0; bq < 4; ++bq) {
+          int rb = 16 * g + 4 * bq;
+          if (rb >= p.L) rb = 0;
+          qt[size_t(g) * 4 + bq] = (at0 + rb * pstep) / p.L;
+        }
+      void *dq = nullptr;
+      if ((rc = upload(qt.data(), qt.size() * sizeof(int), &dq)) != kOk) return rc;
+      pm.qtab = static_cast<int *>(dq);
+    }
     pm.KS = KS;
     pm.NGRP = NGRP;
     pm.Vt = Vt;
@@ -574,6 +586,7 @@ Engine::~Engine()
   }
   for (PolyMf &m : polymf_) {
     if (m.cfm) (void)hipFree(m.cfm);
+    if (m.qtab) (void)hipFree(m.qtab);
     if (m.blk) (void)hipFree(m.blk);
   }
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
@@ -960,6 +973,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, pm.blk, stream_)); prof_end(pp); }
           PolyMfArgs a;
           a.cfm = pm.cfm;
+          a.qtab = pm.qtab;
           a.blk = pm.blk;
           a.B0 = t0;
           a.at0 = at0;

@@ -129,7 +129,7 @@ private:
                 FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   // standalone matrix-pipe polyphase stage (polymf.hip), indexed by the poly stage
-  struct PolyMf { double *cfm = nullptr; FusedBlock *blk = nullptr; int KS = 0, NGRP = 0, Vt = 0, blk_cap = 0; };
+  struct PolyMf { double *cfm = nullptr; int *qtab = nullptr; FusedBlock *blk = nullptr; int KS = 0, NGRP = 0, Vt = 0, blk_cap = 0; };
   std::vector<PolyMf> polymf_;
   struct Pending { long long B0 = 0; int nblocks = 0; };
   struct ProfRec { hipEvent_t e0, e1; bool hot; const char *name; };

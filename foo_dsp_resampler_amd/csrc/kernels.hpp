@@ -193,6 +193,7 @@ hipError_t launch_fused_prep(const FusedPrepArgs &p, FusedBlock *out, hipStream_
 // standalone rational polyphase stage on the matrix pipe (polymf.hip)
 struct PolyMfArgs {
   const double *cfm;     // A operands [16-residue group][k-step][lane], as in FusedArgs
+  const int *qtab;       // window start of every 4-residue block, as in FusedArgs
   const FusedBlock *blk; // per tile: fused_block_info with V = Vt, n = 1, b_offset = 0, clipped to the launch's outputs
   long long B0;          // first tile of the launch: tile B covers stage-input samples [B*Vt, (B+1)*Vt)
   long long at0;         // absolute initial clock of the stage, units 1/polyL

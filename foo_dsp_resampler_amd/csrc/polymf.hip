@@ -28,7 +28,7 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   const FusedBlock fb = a.blk[bl];
   if (fb.cnt <= 0) return; // uniform
   const long long b0 = (a.B0 + bl) * (long long)a.Vt;
-  const int pl = a.polyL, step = a.step, at0 = (int)a.at0;
+  const int pl = a.polyL, step = a.step;
   const int W = a.Vt + a.n + 4; // samples any stored output of this tile can touch
 
   { // stage the window; positions the producer has not written yet read as zero (only unstored outputs see them)
@@ -79,100 +79,87 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
     }
   }
 
+  // Tile walk as in fused_fast.hip: tiles (16-residue group, column step of 4 periods) in group-major order, a contiguous
+  // range per wave; coefficient tile double-buffered a group ahead, window start of a group from the host table, every
+  // store issued straight after its tile under a per-lane range test, next tile's samples always prefetched.
   auto run = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
     char *const obytes = reinterpret_cast<char *>(obase);
-    const int frame_bytes = ofs * 4, period4_bytes = 4 * pl * frame_bytes;
-    constexpr int NW = 4, MAXCS = 4;
+    const int frame_bytes = ofs * 4;
     const int li_lo = -kPmPad, li_hi = W + kPmPad - 4 * KS;
-    const int ncs = (fb.K + 3) >> 2, half0 = (ncs + 1) >> 1;
+    const int ncs = (fb.K + 3) >> 2, nt = a.NGRP * ncs;
+    const int t0 = (nt * wave) >> 2, t1 = (nt * (wave + 1)) >> 2;
+    if (t0 >= t1) return;
+    int g = t0 / ncs, c = t0 - g * ncs;
+    const int g_last = (t1 - 1) / ncs;
+    const int rloc = 4 * bq + hi;
+    const int lane_li = fb.base_li + hi + jq * step;
+    const int lane_ib = jq * pl + rloc - fb.irel_lo; // output index relative to i_lo = lane_ib + 16 g + c * 4 * pl
+    const int cnt = min(irel_hi, fb.K * pl) - fb.irel_lo;
+    const int step4 = 4 * step, pl4 = 4 * pl;
+    const double *const cfm_lane = a.cfm + lane;
+    const int *const qtab_lane = a.qtab + bq;
 
-    double cn_[KS];
-    {
-      const double *cp = a.cfm + (wave >> 1) * (KS * 64);
+    double cc[KS], cn[KS];
+    int qc, qn = 0;
+    auto load_tile = [&](int gg, double (&c_)[KS], int &q_) {
+      const double *cp = cfm_lane + gg * (KS * 64);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) cn_[s] = cp[s * 64 + lane];
-    }
-    // stores of an item are issued at the start of the next one (see fused.hip: one in-order vmcnt)
-    double pA[MAXCS], pB[MAXCS];
-    int pend_n = 0, pend_ib = 0, pend_hi = 0, pend_allv = 0, pend_off = 0;
-    auto flush = [&]() {
-#pragma unroll
-      for (int u = 0; u < MAXCS; ++u) {
-        if (u < pend_n) {
-          const int ib = pend_ib + u * 4 * pl;
-          if (((pend_allv >> u) & 1) || (ib >= fb.irel_lo && ib < pend_hi)) {
-            const int orel = ib - fb.irel_lo;
-            if (FAST) {
-              *reinterpret_cast<float2 *>(obytes + (pend_off + u * period4_bytes)) = make_float2((float)pA[u], (float)pB[u]);
-            } else {
-              const long long oabs = a.out_offset + fb.i_lo + orel;
-              fifo_put(oa, oabs, pA[u]);
-              if (hasb) fifo_put(ob, oabs, pB[u]);
-            }
-          }
-        }
-      }
-      pend_n = 0;
+      for (int s = 0; s < KS; ++s) c_[s] = cp[s * 64];
+      q_ = qtab_lane[gg * 4];
     };
-    for (int it = wave; it < 2 * a.NGRP; it += NW) { // (16-residue group, half of the column steps)
-      const int g = it >> 1, second = (it + (it >> 2)) & 1;
-      int cs0 = second ? half0 : 0, cs1 = second ? ncs : half0;
-      while (cs0 < cs1 && (4 * cs0 + 3) * pl + 16 * g + 15 < fb.irel_lo) ++cs0;
-      while (cs1 > cs0 && 4 * (cs1 - 1) * pl + 16 * g >= irel_hi) --cs1;
-      double ca_[KS];
+    load_tile(g, cc, qc);
+    if (g < g_last) load_tile(g + 1, cn, qn);
+    double2 x0[KS], x1[KS];
+    auto fill = [&](double2 (&x)[KS], int q, int cstep) {
+      const int li = max(li_lo, min(li_hi, lane_li + q + cstep * step4));
+      const double2 *xp = smp + li;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) ca_[s] = cn_[s];
-      flush();
-      {
-        const int nx = it + NW < 2 * a.NGRP ? it + NW : wave;
-        const double *cp = a.cfm + (nx >> 1) * (KS * 64);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) cn_[s] = cp[s * 64 + lane];
+      for (int s = 0; s < KS; ++s) x[s] = xp[4 * s];
+    };
+    fill(x0, qc, c);
+    int left = t1 - t0;
+    auto tile = [&](const double2 (&xc)[KS], double2 (&xn)[KS]) {
+      int cnext = c + 1, gnext = g;
+      if (cnext == ncs) {
+        cnext = 0;
+        gnext = g + 1;
       }
-      int rb = 16 * g + 4 * bq;
-      if (rb >= pl) rb = 0;
-      const int qb = (at0 + rb * step) / pl + fb.base_li + hi + jq * step;
-      const int step4 = 4 * step;
-      double2 x0[KS], x1[KS];
-      auto fill = [&](double2 (&x)[KS], int cs) {
-        const int li = max(li_lo, min(li_hi, qb + cs * step4));
-        const double2 *xp = smp + li;
+      const bool switch_group = gnext != g && left > 1;
+      fill(xn, switch_group ? qn : qc, left > 1 ? cnext : c);
+      double accA = 0.0, accB = 0.0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) x[s] = xp[4 * s];
-      };
-      auto column_step = [&](const double2 (&x)[KS], double &accA, double &accB) {
-        accA = 0.0;
-        accB = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          accA = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].x, accA, 0, 0, 0);
-          accB = __builtin_amdgcn_mfma_f64_4x4x4f64(ca_[s], x[s].y, accB, 0, 0, 0);
-        }
-      };
-      if (cs0 < cs1) fill(x0, cs0);
-#pragma unroll
-      for (int u = 0; u < MAXCS; ++u) {
-        if (cs0 + u < cs1) {
-          if (cs0 + u + 1 < cs1) fill((u & 1) ? x0 : x1, cs0 + u + 1);
-          column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
+      for (int s = 0; s < KS; ++s) {
+        accA = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].x, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].y, accB, 0, 0, 0);
+      }
+      const int ib = lane_ib + 16 * g + c * pl4;
+      if (ib >= 0 && ib < cnt && 16 * g + rloc < pl) {
+        if (FAST) {
+          *reinterpret_cast<float2 *>(obytes + (unsigned)(ib * frame_bytes)) = make_float2((float)accA, (float)accB);
+        } else {
+          const long long oabs = a.out_offset + fb.i_lo + ib;
+          fifo_put(oa, oabs, accA);
+          if (hasb) fifo_put(ob, oabs, accB);
         }
       }
-      const int rD = 16 * g + 4 * bq + hi, k0 = 4 * cs0;
-      pend_n = cs1 - cs0;
-      pend_ib = (k0 + jq) * pl + rD;
-      pend_off = (pend_ib - fb.irel_lo) * frame_bytes;
-      pend_hi = rD < pl ? min(irel_hi, fb.K * pl) : -1;
-      pend_allv = 0;
-      if (16 * g + 15 < pl) {
+      if (switch_group) {
 #pragma unroll
-        for (int u = 0; u < MAXCS; ++u)
-          if (k0 + 4 * u + 3 < fb.K && (k0 + 4 * u) * pl + 16 * g >= fb.irel_lo && (k0 + 4 * u + 3) * pl + 16 * g + 15 < irel_hi)
-            pend_allv |= 1 << u;
+        for (int s = 0; s < KS; ++s) cc[s] = cn[s];
+        qc = qn;
+        if (gnext < g_last) load_tile(gnext + 1, cn, qn);
       }
+      g = gnext;
+      c = cnext;
+      --left;
+    };
+    while (true) {
+      tile(x0, x1);
+      if (left == 0) break;
+      tile(x1, x0);
+      if (left == 0) break;
     }
-    flush();
   };
   if (ofast) run(std::true_type{});
   else run(std::false_type{});

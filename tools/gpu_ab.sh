@@ -7,7 +7,7 @@ cfg=$1; shift
 for round in 1 2; do
 for v in "$@"; do
   if [ "$v" = base ]; then unset RATELIB_AMD_SO; else export RATELIB_AMD_SO=$PWD/foo_dsp_resampler_amd/libratelib_amd_$v.so; fi
-  ${ABENV} python3 bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $O/$v.json 2> $O/$v.err || { echo "$v FAILED"; tail -3 $O/$v.err; }
+  ${ABENV} python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/$v.json 2> $O/$v.err || { echo "$v FAILED"; tail -3 $O/$v.err; }
   python3 -c "
 import json; d=json.load(open('$O/$v.json')); r=d['roofline']; print('%-10s' % '$v', d['value'], r['kernels_ms_per_step'])"
   grep RSMP_ $O/$v.err
