@@ -116,18 +116,22 @@ def cpu_baseline(cfg, seconds_single=4.0, seconds_multi=8.0):
                                                                                threads, seconds_single)}
 
 
-def lookup_traffic(config, streams, frames, kernel):
-    """HBM bytes per launch of `kernel` from the tracked PMC passes (profiles/traffic.json), or None."""
+def lookup_traffic(config, streams, frames, kernels):
+    """HBM bytes per step of `kernels` (one launch each per step) from the tracked PMC passes (profiles/traffic.json);
+    None unless every one of them has a record for exactly this workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             recs = json.load(f)["records"]
     except (OSError, ValueError, KeyError):
         return None
-    for r in recs:
-        if r.get("config") == config and r.get("streams_per_gpu") == streams and r.get("frames_per_push") == frames \
-                and r.get("kernel") == kernel:
-            return r.get("hbm_bytes_per_launch")
-    return None
+    total = 0
+    for k in kernels:
+        hit = [r for r in recs if r.get("config") == config and r.get("streams_per_gpu") == streams and
+               r.get("frames_per_push") == frames and r.get("kernel") == k]
+        if not hit or hit[0].get("hbm_bytes_per_launch") is None:
+            return None
+        total += hit[0]["hbm_bytes_per_launch"]
+    return total
 
 
 def main():
@@ -180,8 +184,7 @@ def main():
     cap = int(P * fo / fi) + 8192
     y = torch.empty((S, cap, nch), device="cuda", dtype=torch.float32)
     torch.cuda.synchronize()
-    # the engine runs on a stream of ours (a NULL handle would mean "the handle's own stream", include/ratelib_amd.h), so
-    # the HIP events below bracket exactly the work of the timed steps
+    # the engine runs on a stream of ours, so the HIP events below bracket exactly the work of the timed steps
     stream = torch.cuda.Stream()
     r.set_stream(stream.cuda_stream)
 
@@ -264,7 +267,10 @@ def main():
                        "out_frames_per_stream": out_frames},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-                         "traffic": lookup_traffic(args.config, S, P, dom["kernel"]),
+                         # PMC bytes of the dominant kernel's launch (fused chain) or of the chain's stage kernels per step
+                         "traffic": (lookup_traffic(args.config, S, P, [dom["kernel"]]) if fused and launches_per_step == 1 else
+                                     lookup_traffic(args.config, S, P, [k["kernel"] for k in chain if k["hot"]])
+                                     if all(k["launches"] == args.steps for k in chain if k["hot"]) else None),
                          "kernel": dom["kernel"],
                          "kernel_time_basis": "dominant kernel (fused chain)" if fused else "sum of the chain's stage kernels",
                          "launches_per_step": launches_per_step,

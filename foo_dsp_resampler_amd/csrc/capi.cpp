@@ -184,7 +184,8 @@ int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t 
 int RRX_set_stream(RR_handle *h, void *hip_stream)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->set_stream(static_cast<hipStream_t>(hip_stream)); });
+  const bool own = hip_stream == RRX_STREAM_OWN;
+  return guarded([&] { return h->eng->set_stream(own ? nullptr : static_cast<hipStream_t>(hip_stream), own); });
 }
 
 int RRX_sync(RR_handle *h)

@@ -596,9 +596,9 @@ Engine::~Engine()
   if (own_) (void)hipStreamDestroy(own_); // never the caller's stream
 }
 
-int Engine::set_stream(hipStream_t s)
+int Engine::set_stream(hipStream_t s, bool own)
 {
-  hipStream_t next = s ? s : own_;
+  hipStream_t next = own ? own_ : s; // s == nullptr is the device's default (legacy) stream, as in every HIP call
   if (next == stream_) return kOk;
   { int rcj = join_side(); if (rcj) return rcj; } // seam kernels still on the side stream belong to the old stream's work
   HIP_TRY(hipEventRecord(ev_switch_, stream_));

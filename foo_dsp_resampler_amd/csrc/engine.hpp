@@ -41,9 +41,10 @@ public:
   size_t isamp_max() const { return plan_.isamp_max; }
   size_t available() const { return size_t(book_.wr.back() - book_.rd.back()); }
 
-  // Use the caller's stream for everything from now on (nullptr: back to the handle's own stream).  Work already
-  // queued on the previous stream is ordered before anything queued later (event on the old stream, wait on the new).
-  int set_stream(hipStream_t s);
+  // Use the caller's stream for everything from now on (nullptr = the default stream, like any HIP call; own = true:
+  // back to the handle's own stream).  Work already queued on the previous stream is ordered before anything queued
+  // later (event on the old stream, wait on the new).  The caller's stream is never destroyed by the handle.
+  int set_stream(hipStream_t s, bool own = false);
   hipStream_t stream() const { return stream_; }
   int sync();
   // test hook: make the n-th device allocation from now on (n >= 1, process-wide) fail with hipErrorOutOfMemory; 0 disarms

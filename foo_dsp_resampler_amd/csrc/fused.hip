@@ -618,8 +618,19 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
     const double *__restrict__ cf = a.tab + (long long)ph * a.n;
     const double *x = win[grp] + (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= . < n-1
     double sum = 0.0;
+    if (a.n == 24) { // Best: the whole coefficient row in flight at once (12 16-byte loads), then the reference's tap order
+      double2 c2[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) c2[j] = reinterpret_cast<const double2 *>(cf)[j];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        sum = fma(c2[j].x, x[2 * j], sum);
+        sum = fma(c2[j].y, x[2 * j + 1], sum);
+      }
+    } else {
 #pragma unroll 8
-    for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
+      for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
+    }
     fifo_put(dst, a.out_offset2 + i, sum);
   }
 }

@@ -158,18 +158,23 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     const int slot = (int)(B & a.seam_mask);
     double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
     double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+    // (the slot tests are wave-uniform: only the slots that can hold a block edge carry per-lane tests and seam stores)
+    const int tail0 = V - nm1; // first sample of the block's tail
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int n = tid + s * T;
-      if (n < V) {
-        if (s < kSA || (s == kSA && tid < kPad)) smp[n] = make_double2(v[s].x, v[s].y);
-        if (n < nm1) {
-          seamA[n] = v[s].x;
-          seamB[n] = v[s].y;
-        }
-        if (n >= V - nm1) {
-          seamA[32 + n - (V - nm1)] = v[s].x;
-          seamB[32 + n - (V - nm1)] = v[s].y;
+      const bool whole = (s + 1) * T <= V;                 // every sample of this slot is valid
+      if (s < kSA || s == kSA) {
+        if (s < kSA ? (whole || n < V) : (tid < kPad && n < V)) smp[n] = make_double2(v[s].x, v[s].y);
+      }
+      if (s == 0 && tid < nm1) {
+        seamA[tid] = v[0].x;
+        seamB[tid] = v[0].y;
+      }
+      if ((s + 1) * T > tail0 && s * T < V) {              // the tail's slot(s)
+        if (n >= tail0 && n < V) {
+          seamA[32 + n - tail0] = v[s].x;
+          seamB[32 + n - tail0] = v[s].y;
         }
       }
     }

@@ -203,7 +203,12 @@ class Resampler:
         return self.L.RRX_available(self.h)
 
     def set_stream(self, hip_stream_ptr):
-        _check(self.L.RRX_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "RRX_set_stream")
+        """hipStream_t as an integer (torch: stream.cuda_stream); 0 / None = the default stream."""
+        _check(self.L.RRX_set_stream(self.h, C.c_void_p(hip_stream_ptr or 0)), "RRX_set_stream")
+
+    def use_own_stream(self):
+        """Back to the stream the handle created for itself (RRX_STREAM_OWN)."""
+        _check(self.L.RRX_set_stream(self.h, C.c_void_p(C.c_size_t(-1).value)), "RRX_set_stream")
 
     def sync(self):
         _check(self.L.RRX_sync(self.h), "RRX_sync")

@@ -37,10 +37,12 @@ int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, f
 int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp);
 int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen);
 
-/* Use the caller's hipStream_t (passed as void*) for all work of this handle from now on; NULL restores the
- * handle's own stream.  The caller keeps ownership of its stream (RR_close never destroys it); work already queued
- * on the previous stream is ordered before the work queued after the switch.  RRX_sync blocks until everything
- * enqueued so far has finished. */
+/* Use the caller's hipStream_t (passed as void*) for all work of this handle from now on.  NULL is the device's default
+ * stream, as in every HIP call (it is also what PyTorch's default stream is); RRX_STREAM_OWN restores the stream the
+ * handle created for itself at RR_open, which is what a handle uses until this is called.  The caller keeps ownership of
+ * its stream (RR_close never destroys it); work already queued on the previous stream is ordered before the work queued
+ * after the switch.  RRX_sync blocks until everything enqueued so far has finished. */
+#define RRX_STREAM_OWN ((void *)(~(size_t)0))
 int RRX_set_stream(RR_handle *h, void *hip_stream);
 int RRX_sync(RR_handle *h);
 

@@ -177,7 +177,7 @@ def test_device_pointer_api_and_full_size_properties():
     g = torch.Generator(device="cuda").manual_seed(1)
     x = (torch.rand((S, n, nch), generator=g, device="cuda") - 0.5)
     r = F.Resampler(44100, 96000, nch=nch, nstreams=S)
-    torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * 96000 / 44100) + 4096
     y = torch.zeros((S, cap, nch), device="cuda")
     iu, og = r.flow_device(x, n, y, cap)
@@ -208,7 +208,7 @@ def test_bench_workload_against_oracle():
     g = torch.Generator(device="cuda").manual_seed(7)
     x = (torch.rand((S, n, nch), generator=g, device="cuda") - 0.5)
     r = F.Resampler(fi, fo, nch=nch, nstreams=S)
-    torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * fo / fi) + 4096
     y = torch.zeros((S, cap, nch), device="cuda")
     iu, og = r.flow_device(x, n, y, cap)

@@ -28,7 +28,7 @@ def test_cfg4_per_gpu_shard_against_oracle():
     nch, fi, fo, n = 2, 44100, 48000, 60000
     x = torch.stack([torch.from_numpy(lcg_noise(n, nch, 12345 + first + s)) for s in range(S)]).cuda()
     r = F.Resampler(fi, fo, nch=nch, nstreams=S)
-    torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * fo / fi) + 4096
     y = torch.zeros((S, cap, nch), device="cuda")
     got = 0
@@ -92,7 +92,7 @@ def test_failed_push_poisons_the_handle():
 
 def test_set_stream_does_not_take_ownership():
     """RRX_set_stream with a non-default stream: results equal the default-stream run, closing the handle leaves the
-    caller's stream usable, NULL restores the handle's own stream, and work is ordered across the switch."""
+    caller's stream usable, RRX_STREAM_OWN restores the handle's own stream, and work is ordered across the switch."""
     torch = pytest.importorskip("torch")
     fi, fo, nch, n = 44100, 96000, 2, 50000
     x = torch.from_numpy(lcg_noise(n, nch, 5)).cuda()
@@ -104,7 +104,7 @@ def test_set_stream_does_not_take_ownership():
     torch.cuda.synchronize()
     r.set_stream(side.cuda_stream)
     iu, og = r.flow_device(x[:30000].contiguous(), 30000, y, cap)
-    r.set_stream(None)                                   # back to the handle's own stream, ordered after the work above
+    r.use_own_stream()                                   # back to the handle's own stream, ordered after the work above
     iu2, og2 = r.flow_device(x[30000:].contiguous(), n - 30000, y[og:], cap - og)
     r.set_stream(side.cuda_stream)
     r.drain()

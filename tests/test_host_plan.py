@@ -22,6 +22,7 @@ def test_library_exports_every_declared_symbol():
     for h in ("ratelib.h", "ratelib_amd.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"^\s*#define.*$", "", txt, flags=re.M)   # macros (RRX_STREAM_OWN) are not exported symbols
         declared |= set(re.findall(r"\b((?:RRX?_|init_|close_)[A-Za-z_]+)\s*\(", txt))
     assert declared == set(F.EXPECTED_SYMBOLS), declared ^ set(F.EXPECTED_SYMBOLS)
 

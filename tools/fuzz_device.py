@@ -37,7 +37,7 @@ def main(n_cases, seed):
         g = torch.Generator(device="cuda").manual_seed(int(rng.randint(1, 1 << 30)))
         x = torch.rand((S, frames, nch), generator=g, device="cuda") - 0.5
         r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
-        torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
         outs = []
         pos = 0
         while pos < frames:

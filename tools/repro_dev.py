@@ -14,7 +14,7 @@ for trial in range(12):
     g = torch.Generator(device="cuda").manual_seed(trial + 1)
     x = torch.rand((S, frames, nch), generator=g, device="cuda") - 0.5
     r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
-    torch.cuda.synchronize()  # inputs were produced on torch's stream; the handle runs on its own (ratelib_amd.h: RRX_set_stream)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     outs, pos, log = [], 0, []
     while pos < frames:
         n = min(frames - pos, int(rng.randint(1, min(frames, r.isamp_max) + 1)))
