@@ -269,8 +269,8 @@ def main():
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
                          # PMC bytes of the dominant kernel's launch (fused chain) or of the chain's stage kernels per step
                          "traffic": (lookup_traffic(args.config, S, P, [dom["kernel"]]) if fused and launches_per_step == 1 else
-                                     lookup_traffic(args.config, S, P, [k["kernel"] for k in chain if k["hot"]])
-                                     if all(k["launches"] == args.steps for k in chain if k["hot"]) else None),
+                                     lookup_traffic(args.config, S, P, [k["kernel"] for k in chain])
+                                     if all(k["launches"] == args.steps for k in chain) else None),
                          "kernel": dom["kernel"],
                          "kernel_time_basis": "dominant kernel (fused chain)" if fused else "sum of the chain's stage kernels",
                          "launches_per_step": launches_per_step,

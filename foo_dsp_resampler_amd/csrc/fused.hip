@@ -589,49 +589,45 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
 // window samples come from the seam ring.  One workgroup = one boundary x 8 channels, 32 lanes per channel;
 // the 2*(n-1) samples around the boundary are staged in LDS first so that the tap loop has no dependent
 // global loads (the coefficient rows are independent loads, issued 8 taps ahead).
+// One workgroup = one boundary x kSeamC channels.  Every channel needs the same coefficient rows (the phase depends on the
+// output index only), so the rows of the boundary's outputs are staged in LDS once per workgroup next to the channels'
+// [tail | head] windows (one row copy per CHANNEL used to make this kernel an L2-bandwidth problem: 700 MB of row reads per
+// launch of the bench workload).  The per-boundary output range and the first output's window / phase come from the block
+// table (fused_block_info): no 64-bit divisions here.
+constexpr int kSeamC = 64, kSeamWin = 2 * 31 + 3, kSeamOut = 64; // window row padded to an odd number of doubles
 __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
 {
-  __shared__ double win[8][64];
-  const long long B = a.d.B0 + blockIdx.x;
-  const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-  const int c = blockIdx.y * 8 + grp;
-  const int nm1 = a.n - 1, pl = a.polyL, step = a.step;
+  __shared__ double win[kSeamC][kSeamWin];
+  __shared__ double cfs[kSeamOut][32];
+  const int bl = blockIdx.x, c0 = blockIdx.y * kSeamC, tid = threadIdx.x;
+  const long long B = a.d.B0 + bl;
+  const int nm1 = a.n - 1, pl = a.polyL, step = a.step, n = a.n;
   const int slots = a.seam_mask + 1;
-  if (c < a.d.C) {
+  const int nc = min(kSeamC, a.d.C - c0);
+  const FusedBlock fb = a.blk[bl];
+  const int cnt = min((int)(fb.i_lo - fb.seam_i0), kSeamOut); // at most ~(n - 1) * L / step + 1 outputs per boundary (host-checked <= 64)
+  for (int idx = tid; idx < nc * 2 * nm1; idx += 256) {
+    const int cl = idx / (2 * nm1), k = idx - cl * (2 * nm1), c = c0 + cl;
     const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
     const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
-    if (l32 < nm1) {
-      win[grp][l32] = B == 0 ? 0.0 : tail[l32];
-      win[grp][nm1 + l32] = head[l32];
-    }
+    win[cl][k] = k < nm1 ? (B == 0 ? 0.0 : tail[k]) : head[k - nm1];
+  }
+  for (int idx = tid; idx < cnt * n; idx += 256) {
+    const int u = idx / n, j = idx - u * n;
+    const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
+    const unsigned ph = t % (unsigned)pl;
+    cfs[u][j] = a.tab[(long long)ph * n + j];
   }
   __syncthreads();
-  if (c >= a.d.C) return;
-  const long long b = a.b_offset + B * a.d.V; // first stage-1 index of block B
-  const long long num0 = (b - nm1) * pl - a.at0, num1 = b * pl - a.at0;
-  const long long i0 = num0 <= 0 ? 0 : (num0 + step - 1) / step;
-  const long long i1 = num1 <= 0 ? 0 : (num1 + step - 1) / step;
-  const ChanRef dst = chan_ref(out, c);
-  for (long long i = i0 + l32; i < i1; i += 32) {
-    const long long ai = a.at0 + i * step, q = ai / pl;
-    const int ph = (int)(ai - q * pl);
-    const double *__restrict__ cf = a.tab + (long long)ph * a.n;
-    const double *x = win[grp] + (int)(q - (b - nm1)); // window start inside [tail | head], 0 <= . < n-1
+  for (int idx = tid; idx < cnt * nc; idx += 256) {
+    const int u = idx / nc, cl = idx - u * nc; // neighbouring lanes: neighbouring channels of one output
+    const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step;
+    const double *x = win[cl] + fb.seam_q0 + (int)(t / (unsigned)pl); // window start inside [tail | head], 0 <= . < n-1
+    const double *cf = cfs[u];
     double sum = 0.0;
-    if (a.n == 24) { // Best: the whole coefficient row in flight at once (12 16-byte loads), then the reference's tap order
-      double2 c2[12];
-#pragma unroll
-      for (int j = 0; j < 12; ++j) c2[j] = reinterpret_cast<const double2 *>(cf)[j];
-#pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        sum = fma(c2[j].x, x[2 * j], sum);
-        sum = fma(c2[j].y, x[2 * j + 1], sum);
-      }
-    } else {
 #pragma unroll 8
-      for (int j = 0; j < a.n; ++j) sum = fma(cf[j], x[j], sum);
-    }
-    fifo_put(dst, a.out_offset2 + i, sum);
+    for (int j = 0; j < n; ++j) sum = fma(cf[j], x[j], sum); // the reference's tap order
+    fifo_put(chan_ref(out, c0 + cl), a.out_offset2 + fb.seam_i0 + u, sum);
   }
 }
 
@@ -681,7 +677,7 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
 hipError_t launch_seam(bool dst_f32, const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st)
 {
   const AnyView out = make_view(dst_f32, df, dd);
-  dim3 sgrid(a.d.nblocks, (a.d.C + 7) / 8), sblock(256);
+  dim3 sgrid(a.d.nblocks, (a.d.C + kSeamC - 1) / kSeamC), sblock(256);
   hipLaunchKernelGGL(seam_kernel, sgrid, sblock, 0, st, out, a);
   return hipGetLastError();
 }

@@ -73,6 +73,10 @@ struct FusedBlock {
   int base_li;    // kk_lo * step - b0: window start of (period kk_lo, residue r) is qr(r) + base_li
   int K;          // periods touched by [i_lo, i_lo + cnt)
   int KA;         // matrix-pipe variant: periods [0, KA) are computed from the first LDS image, the rest from the second
+  // seam outputs in front of this block (window straddles blocks B-1 | B): indices [seam_i0, i_lo); output seam_i0 has
+  // phase seam_ph0 and its window starts seam_q0 samples into the [tail of B-1 | head of B] image (seam_kernel)
+  long long seam_i0;
+  int seam_q0, seam_ph0;
 };
 // Matrix-pipe variant of the fused kernel (N = 4096, 256 threads): the block's samples sit in LDS in two rounds,
 // round A = register slots [0, kFusedSA) of the inverse FFT (samples [0, 256*kFusedSA) plus a 32-sample margin),
@@ -107,6 +111,14 @@ __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, i
   fb.base_li = int(kk_lo * p.step - b0);
   fb.K = fb.cnt > 0 ? int((ihi - 1) / p.polyL - kk_lo) + 1 : 0;
   fb.KA = fb.K;
+  { // first output whose window starts at or behind the previous block's tail: (b0 - (n - 1)) * L - at0 over step, rounded up
+    const long long ns = (b0 - (p.n - 1)) * p.polyL - p.at0;
+    const long long s0 = ns <= 0 ? 0 : (ns + p.step - 1) / p.step;
+    const long long a0 = p.at0 + s0 * p.step, q0 = a0 / p.polyL;
+    fb.seam_i0 = s0;
+    fb.seam_q0 = int(q0 - (b0 - (p.n - 1)));
+    fb.seam_ph0 = int(a0 - q0 * p.polyL);
+  }
   if (p.two_round && p.V > kFusedSA * 256) { // periods whose (padded) windows end inside the first LDS image
     const int a_hi = kFusedSA * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
     const int ka = num < 0 ? 0 : num / p.step + 1;
