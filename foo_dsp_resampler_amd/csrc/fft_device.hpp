@@ -137,9 +137,19 @@ constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) 
 // MODE 1 ("split"): real and imaginary halves in two rounds of 8-byte elements (M*8 bytes).
 // MODE 2 ("halves"): destinations [0, M/2) first, then [M/2, M), 16-byte elements both times (M*8 bytes plus
 //         padding): same LDS traffic as mode 0, two more barriers, half the footprint.
-template <int T, int MODE, int PADR = 1>
+// RSMP_EXP_NOBAR (timing experiments only, results are WRONG): exchanges after the first one of a transform run without
+// their workgroup barriers -- an upper bound for what wave-local exchanges could save.
+#ifndef RSMP_EXP_NOBAR
+#define RSMP_EXP_NOBAR 0
+#endif
+template <bool BAR> __device__ __forceinline__ void rsmp_xbar()
+{
+  if (BAR) (__syncthreads)();
+}
+template <int T, int MODE, int PADR = 1, bool BAR = true>
 __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16], int tid, bool active, double *lds)
 {
+#define __syncthreads() rsmp_xbar<BAR>()
   if (MODE == 2) {
     // a thread's 16 values may all belong to the second round, so the first round's reads need their own
     // registers until the second round's writes are out
@@ -214,6 +224,7 @@ __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16],
   }
 }
 
+#undef __syncthreads
 // One pass.  PF > 0 (twiddle prefetch): this pass's twiddles were loaded into `wcur` ahead of the previous
 // exchange, and the first PF twiddles of the NEXT pass (table `twn`, butterfly stride NSN) are loaded into `wnext`
 // before this pass's exchange, so their L2 round trip runs behind the LDS round trip instead of after it.
@@ -254,7 +265,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
       for (int r = 0; r < R; ++r) pos[t + NB * r] = (j - k) * R + k + r * NS;
     }
-    lds_exchange<T, MODE, (NS == 1 && MODE != 1) ? R : 1>(v, pos, tid, active, lds);
+    lds_exchange<T, MODE, (NS == 1 && MODE != 1) ? R : 1, !(RSMP_EXP_NOBAR && NS > 1)>(v, pos, tid, active, lds);
   }
 }
 
@@ -327,7 +338,7 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
         for (int r = 0; r < R; ++r) l2[lds_phys<PADR>((j - k) * R + k + r * NS)] = make_double2(u[t + NB * r].x, u[t + NB * r].y);
       }
     }
-    __syncthreads();
+    if (!(RSMP_EXP_NOBAR >= 2 && NS > 1)) __syncthreads();
     if (active) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -335,7 +346,7 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
         u[s] = {q.x, q.y};
       }
     }
-    __syncthreads();
+    if (!(RSMP_EXP_NOBAR >= 2 && NS > 1)) __syncthreads();
   }
 }
 

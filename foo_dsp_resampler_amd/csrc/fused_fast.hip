@@ -27,6 +27,10 @@
 #ifndef RSMP_FAST_FWD8
 #define RSMP_FAST_FWD8 1
 #endif
+// wave priority by phase: 1 = FFT phases above the polyphase phase, 2 = the other way round (experiments)
+#ifndef RSMP_PRIO
+#define RSMP_PRIO 0
+#endif
 #ifndef RSMP_PFW
 #define RSMP_PFW 15
 #endif
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
   const int nm1 = a.n - 1;
 
+  if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
   // RSMP_STAMPS=1: per-phase cycle sums of wave 0 (s_memtime) in one workgroup of 64, printed when the handle closes
   const bool stamping = a.stamps && (blockIdx.x & 63) == 5;
   unsigned long long tstamp = stamping ? __builtin_readcyclecounter() : 0;
@@ -272,6 +277,8 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   };
 
   const bool run = fb.cnt > 0;
+  if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+  if (RSMP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   // round A: periods whose windows end inside the samples written above
   if (run) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * KS);
   RSMP_STAMP(6)
