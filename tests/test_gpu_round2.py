@@ -154,3 +154,36 @@ def test_non_linear_phase_measured_parity():
         measured = json.load(f)
     for k, v in out.items():
         assert v["rel_rms"] <= 4.0 * measured[k]["rel_rms"], (k, v, measured[k])
+
+
+def test_long_blocks_many_items_per_push():
+    """One push that spans more (block, pair) items than one round of the four-step workspaces holds (dftbig.hip:
+    ws_items), so launch_dft_big runs several rounds: 32768-point blocks, stereo, 330 000 frames in a single push."""
+    fi, fo, bw = 22050, 8000, 99.0
+    plan = F.describe_plan(fi, fo, bandwidth=bw)
+    assert any(s["kind"] == "dft" and s["dft_length"] == 32768 for s in plan["stages"]), plan
+    x = lcg_noise(330000, 2, 51)
+    got = F.Resampler(fi, fo, 2, bandwidth=bw).process(x)           # one push of isamp_max or less
+    ref = Oracle(fi, fo, 2, bandwidth=bw).process(x)
+    assert got.shape == ref.shape
+    assert_parity(got, ref)
+
+
+def test_profile_report_names_the_kernels_the_dispatch_picked():
+    """RRX_profile_report: per-kernel HIP-event records with the instance names rocprofv3 would print; the lean kernel
+    serves a device-resident stereo push, the generic one a host push (its output goes to the ring)."""
+    torch = pytest.importorskip("torch")
+    r = F.Resampler(44100, 96000, nch=2, nstreams=4)
+    x = torch.rand((4, 60000, 2), device="cuda") - 0.5
+    y = torch.empty((4, 140000, 2), device="cuda")
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.profile(True)
+    r.flow_device(x, 60000, y, 140000)
+    rep = r.profile_report()
+    names = {k["kernel"] for k in rep}
+    assert "rsmp::fused_fast_kernel<11, 7>" in names and "rsmp::seam_kernel" in names, names
+    assert all(k["launches"] >= 1 and k["ms"] > 0 for k in rep)
+    r.push(x.cpu().numpy())                                         # host path: output into the ring -> generic kernel
+    names = {k["kernel"] for k in r.profile_report()}
+    assert "rsmp::fused_kernel<12, 11, 2, 7, true>" in names, names
+    r.profile(False)
