@@ -298,11 +298,14 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       int qb_min = at0 / p.L, qb_max = qb_min;
       for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
       // ... and at most 32 periods per block (4 column steps per item), enough phases to fill 16-row tiles
-      // ... and the zero padding must stay small: taps are padded to 4*KS, phases to 16*NGRP.  Measured: 44.1k->48k (24 of 32
-      // taps, 80 of 80 rows = 75 % useful) 3.48 ms against 4.87 ms for the vector variant; 96k->44.1k (24 of 32 taps and 147 of
-      // 160 rows = 69 %) 3.90 ms against 3.74 ms, so that chain stays on the vector variant.
-      const bool dense = double(p.n) * p.L >= 0.72 * (4.0 * KS) * (16.0 * NGRP);
-      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && dense;
+      // ... and the four periods of a tile (lanes j = 0..3 of a B read, `step` samples apart) must not fall on the same LDS
+      // banks: 16-byte samples, 16 of them per bank row, so j*step mod 16 has to take four values.  96k->44.1k (step 320)
+      // fails that -- every ds_read_b128 a 4-way conflict, measured 3.90 ms against 3.74 ms for the vector variant.
+      bool lanes_spread = true;
+      for (int j1 = 0; j1 < 4; ++j1)
+        for (int j2 = j1 + 1; j2 < 4; ++j2)
+          if (((j2 - j1) * pstep) % 16 == 0) lanes_spread = false;
+      const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && lanes_spread;
       if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)
@@ -1022,6 +1025,15 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
         a.tab_lds = tab_lds;
         a.coop = sp.order >= 1 && sp.n % 8 == 0 && !getenv("RSMP_NO_POLYCOOP");
+        a.shared_rows = 0;
+        if (sp.order >= 1 && !getenv("RSMP_NO_POLYI")) { // the channels of a handle share the clock: share the interpolated rows
+          const double wl = 128 * in_per_out + sp.n + 4; // window of a 128-output tile (kPolyiTile)
+          if ((128.0 * sp.n + 16.0 * (wl + 1)) * 8 <= 150.0 * 1024) { // rows + 16 channel windows must fit LDS
+            a.shared_rows = 1;
+            a.tile = 128;
+            a.win = int(wl) | 1;
+          }
+        }
         const int pi = prof_begin(false);
         const char *kn = nullptr;
         HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,

@@ -410,6 +410,65 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_coop_kernel(Any
   }
 }
 
+// Interpolated polyphase stage (orders 1-3), SHARED-ROW variant.  All channels of a handle run on one clock
+// (rate_base.h:533-540: every channel gets the same rate_t parameters), so output i has the same phase and the same
+// interpolation fraction in every channel: the interpolated coefficient row w_i[j] = Horner(coefs[phase_i][j], x_i)
+// (rate_filters_generic.h:416-424) depends on i only.  A workgroup computes the rows of a tile of kPolyiTile outputs ONCE
+// (into LDS) and applies them to kPolyiCh channels whose windows are staged next to them: the table reads (768 B per row at
+// Best, a different row per output) and the Horner work are paid once per kPolyiCh channels instead of once per channel.
+// Taps are summed in the reference's order (no cross-lane reduction).
+constexpr int kPolyiTile = 128, kPolyiCh = 16;
+template <int ORDER> __global__ __launch_bounds__(256) void polyi_kernel(AnyView in, AnyView out, PolyArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int tid = threadIdx.x, n = a.n;
+  const long long i0 = (long long)blockIdx.x * kPolyiTile;
+  const int cnt = (int)min((long long)kPolyiTile, a.count - i0);
+  const int c0 = blockIdx.y * kPolyiCh, nc = min(kPolyiCh, a.C - c0);
+  const long long A0 = a.at + i0 * a.step, A1 = a.at + (i0 + cnt - 1) * a.step;
+  const long long q0 = A0 >> 32, q1 = A1 >> 32;
+  const int wlen = (int)(q1 - q0) + n;
+  const int wstride = a.win;          // doubles per channel window, odd (bank spread across channels)
+  double *wrow = sh;                  // [kPolyiTile][n]
+  double *win = sh + kPolyiTile * n;  // [kPolyiCh][wstride]
+  for (int idx = tid; idx < nc * wlen; idx += 256) {
+    const int cl = idx / wlen, k = idx - cl * wlen;
+    win[cl * wstride + k] = fifo_get(chan_ref(in, c0 + cl), a.rd + q0 + k);
+  }
+  for (int idx = tid; idx < cnt * n; idx += 256) {
+    const int u = idx / n, j = idx - u * n;
+    const long long A = a.at + (i0 + u) * a.step;
+    const unsigned frac = (unsigned)A;
+    const int ph = (int)(frac >> (32 - a.phase_bits));
+    const double t = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
+    const double *__restrict__ cf = a.tab + ((long long)ph * n + j) * (ORDER + 1);
+    double w;
+    if constexpr (ORDER == 3) {
+      const double2 c01 = *reinterpret_cast<const double2 *>(cf), c23 = *reinterpret_cast<const double2 *>(cf + 2);
+      w = fma(fma(fma(c01.x, t, c01.y), t, c23.x), t, c23.y);
+    } else if constexpr (ORDER == 1) {
+      const double2 c01 = *reinterpret_cast<const double2 *>(cf);
+      w = fma(c01.x, t, c01.y);
+    } else {
+      w = cf[0];
+#pragma unroll
+      for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[o]);
+    }
+    wrow[u * n + j] = w;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < cnt * nc; idx += 256) {
+    const int u = idx / nc, cl = idx - u * nc; // neighbouring lanes: neighbouring channels of one output (rows broadcast)
+    const long long A = a.at + (i0 + u) * a.step;
+    const double *x = win + cl * wstride + (int)((A >> 32) - q0);
+    const double *w = wrow + u * n;
+    double sum = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < n; ++j) sum = fma(w[j], x[j], sum);
+    fifo_put(chan_ref(out, c0 + cl), a.out_abs + i0 + u, sum);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Half-band stage: y[i] = .5 x[c] + sum_k coef[k] (x[c-(2k+1)] + x[c+(2k+1)]),  c = rd + pre + 2 i
 // One workgroup = a tile of kHalfTile outputs of one channel.  Its 2*tile + 4*ncoef input samples are staged in LDS
@@ -540,6 +599,22 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
   const long long tiles = (a.count + a.tile - 1) / a.tile;
   dim3 grid((unsigned)tiles, a.C), block(256);
   const size_t lds_bytes = sizeof(double) * (size_t(a.win) + (order == 0 && a.tab_lds ? size_t(a.L) * a.n : 0));
+  if (order >= 1 && a.shared_rows) { // rows shared by the channels of a workgroup (polyi_kernel)
+    static const char *const pn[4] = {"", "rsmp::polyi_kernel<1>", "rsmp::polyi_kernel<2>", "rsmp::polyi_kernel<3>"};
+    if (kname) *kname = pn[order];
+    const long long ptiles = (a.count + kPolyiTile - 1) / kPolyiTile;
+    dim3 pgrid((unsigned)ptiles, (a.C + kPolyiCh - 1) / kPolyiCh);
+    const size_t pl = sizeof(double) * (size_t(kPolyiTile) * a.n + size_t(kPolyiCh) * a.win);
+    auto set_attr = [&](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(pl)); };
+    hipError_t e = hipSuccess;
+    switch (order) {
+      case 1: e = set_attr(reinterpret_cast<const void *>(&polyi_kernel<1>)); if (e == hipSuccess) hipLaunchKernelGGL(polyi_kernel<1>, pgrid, block, pl, st, in, out, a); break;
+      case 2: e = set_attr(reinterpret_cast<const void *>(&polyi_kernel<2>)); if (e == hipSuccess) hipLaunchKernelGGL(polyi_kernel<2>, pgrid, block, pl, st, in, out, a); break;
+      case 3: e = set_attr(reinterpret_cast<const void *>(&polyi_kernel<3>)); if (e == hipSuccess) hipLaunchKernelGGL(polyi_kernel<3>, pgrid, block, pl, st, in, out, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return e != hipSuccess ? e : hipGetLastError();
+  }
   if (order >= 1 && a.coop) {
     switch (order) {
       case 1: hipLaunchKernelGGL(poly_coop_kernel<1>, grid, block, lds_bytes, st, in, out, a); break;

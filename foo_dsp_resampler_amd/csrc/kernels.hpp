@@ -177,6 +177,8 @@ struct PolyArgs {
   int C, n, L, phase_bits, tile, win;
   int tab_lds;           // order 0: copy the [L][n] table into LDS behind the window (it fits)
   int coop;              // orders 1-3: 8 lanes per output (poly_coop_kernel); needs n % 8 == 0
+  int shared_rows;       // orders 1-3: interpolated rows computed once per tile and shared by 16 channels (polyi_kernel);
+                         // `win` is then the per-channel window stride in doubles (odd)
 };
 
 struct HalfArgs {
