@@ -605,7 +605,14 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
     const long long ptiles = (a.count + kPolyiTile - 1) / kPolyiTile;
     dim3 pgrid((unsigned)ptiles, (a.C + kPolyiCh - 1) / kPolyiCh);
     const size_t pl = sizeof(double) * (size_t(kPolyiTile) * a.n + size_t(kPolyiCh) * a.win);
-    auto set_attr = [&](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(pl)); };
+    // (idempotent; the size only grows with the stage's window, so raising the limit to 150 KB once per instance is enough)
+    static std::atomic<int> attr_done{0};
+    auto set_attr = [&](const void *fn) {
+      if (attr_done.load(std::memory_order_acquire) & (1 << order)) return hipSuccess;
+      hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (ea == hipSuccess) attr_done.fetch_or(1 << order, std::memory_order_release);
+      return ea;
+    };
     hipError_t e = hipSuccess;
     switch (order) {
       case 1: e = set_attr(reinterpret_cast<const void *>(&polyi_kernel<1>)); if (e == hipSuccess) hipLaunchKernelGGL(polyi_kernel<1>, pgrid, block, pl, st, in, out, a); break;

@@ -187,3 +187,17 @@ def test_profile_report_names_the_kernels_the_dispatch_picked():
     names = {k["kernel"] for k in r.profile_report()}
     assert "rsmp::fused_kernel<12, 11, 2, 7, true>" in names, names
     r.profile(False)
+
+
+@pytest.mark.parametrize("fi,fo,kw", [(44100, 48001, {}), (96000, 44101, {}), (44100, 48001, {"quality": 1})])
+def test_interpolated_polyphase_rows_shared_across_channel_groups(fi, fo, kw):
+    """Irrational ratios (vpoly1-3, rate_filters_generic.h:311-504): polyi_kernel computes the interpolated coefficient
+    rows of a tile once and applies them to 16 channels at a time; 7 streams x 5 channels = 35 channels make two full
+    groups and a partial one.  Every stream against the oracle, several pushes."""
+    S, nch, n = 7, 5, 21000
+    xs = np.stack([lcg_noise(n, nch, 700 + s) for s in range(S)])
+    got = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw).process(xs, chunk=6500)
+    for s in range(S):
+        ref = Oracle(fi, fo, nch, **kw).process(xs[s], chunk=6500)
+        assert got[s].shape == ref.shape
+        assert_parity(got[s], ref)
