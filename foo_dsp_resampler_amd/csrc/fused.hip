@@ -269,8 +269,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
     // (the last FFT pass exchanged nothing, and the exchange before it ended with a barrier)
     {
       const int slot = (int)(B & a.seam_mask);
-      double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
-      double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+      double *seamA = a.seam + ((long long)(slot * (a.d.C + 1) + ca) * 2) * 32;
+      double *seamB = a.seam + ((long long)(slot * (a.d.C + 1) + cb) * 2) * 32;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int n = tid + s * T;
@@ -602,14 +602,13 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
   const int bl = blockIdx.x, c0 = blockIdx.y * kSeamC, tid = threadIdx.x;
   const long long B = a.d.B0 + bl;
   const int nm1 = a.n - 1, pl = a.polyL, step = a.step, n = a.n;
-  const int slots = a.seam_mask + 1;
   const int nc = min(kSeamC, a.d.C - c0);
   const FusedBlock fb = a.blk[bl];
   const int cnt = min((int)(fb.i_lo - fb.seam_i0), kSeamOut); // at most ~(n - 1) * L / step + 1 outputs per boundary (host-checked <= 64)
   for (int idx = tid; idx < nc * 2 * nm1; idx += 256) {
     const int cl = idx / (2 * nm1), k = idx - cl * (2 * nm1), c = c0 + cl;
-    const double *tail = a.seam + ((long long)(c * slots + (int)((B - 1) & a.seam_mask)) * 2 + 1) * 32;
-    const double *head = a.seam + ((long long)(c * slots + (int)(B & a.seam_mask)) * 2) * 32;
+    const double *tail = a.seam + ((long long)((int)((B - 1) & a.seam_mask) * (a.d.C + 1) + c) * 2 + 1) * 32;
+    const double *head = a.seam + ((long long)((int)(B & a.seam_mask) * (a.d.C + 1) + c) * 2) * 32;
     win[cl][k] = k < nm1 ? (B == 0 ? 0.0 : tail[k]) : head[k - nm1];
   }
   for (int idx = tid; idx < cnt * n; idx += 256) {

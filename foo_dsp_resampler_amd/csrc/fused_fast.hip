@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   const int ca = 2 * pair, cb = ca + 1;
   {
     const int slot = (int)(B & a.seam_mask);
-    double *seamA = a.seam + ((long long)(ca * (a.seam_mask + 1) + slot) * 2) * 32;
-    double *seamB = a.seam + ((long long)(cb * (a.seam_mask + 1) + slot) * 2) * 32;
+    double *seamA = a.seam + ((long long)(slot * (a.d.C + 1) + ca) * 2) * 32;
+    double *seamB = a.seam + ((long long)(slot * (a.d.C + 1) + cb) * 2) * 32;
     // (the slot tests are wave-uniform: only the slots that can hold a block edge carry per-lane tests and seam stores)
     const int tail0 = V - nm1; // first sample of the block's tail
 #pragma unroll

@@ -137,7 +137,7 @@ struct FusedArgs {
   DftArgs d;             // the FFT-FIR part (out_offset unused)
   const double *tab;     // polyphase table [phase][tap]
   const double *cft;     // per-thread coefficient tiles [tap < 32][g < 2][thread], shifted + zero padded
-  double *seam;          // [channel][slot][head|tail][32] stage-1 samples at block edges
+  double *seam;          // [slot][channel (C + 1 of them)][head|tail][32] stage-1 samples at block edges
   long long at0;         // absolute initial clock of the poly stage, units 1/polyL
   long long b_offset;    // preload of the stage-1 fifo (absolute index of the first FFT output)
   long long out_offset2; // preload of the fifo after the poly stage
