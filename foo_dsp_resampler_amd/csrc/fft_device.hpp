@@ -139,6 +139,9 @@ constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) 
 //         padding): same LDS traffic as mode 0, two more barriers, half the footprint.
 // RSMP_EXP_NOBAR (timing experiments only, results are WRONG): exchanges after the first one of a transform run without
 // their workgroup barriers -- an upper bound for what wave-local exchanges could save.
+#ifndef RSMP_EXP_TWLOAD
+#define RSMP_EXP_TWLOAD 0
+#endif
 #ifndef RSMP_EXP_NOBAR
 #define RSMP_EXP_NOBAR 0
 #endif
@@ -228,7 +231,11 @@ __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16],
 // One pass.  PF > 0 (twiddle prefetch): this pass's twiddles were loaded into `wcur` ahead of the previous
 // exchange, and the first PF twiddles of the NEXT pass (table `twn`, butterfly stride NSN) are loaded into `wnext`
 // before this pass's exchange, so their L2 round trip runs behind the LDS round trip instead of after it.
-template <int LOG2M, int R, int NS, int DIR, int MODE, bool LAST, int PF = 0, int NSN = 1>
+// TWGEN: only the twiddles w^1, w^2, w^4, w^8 of a butterfly are loaded; the other eleven are products of two of them
+// (w^3 = w^1 w^2, w^5 = w^4 w^1, w^6 = w^4 w^2, w^7 = w^4 w^3, w^(8+m) = w^8 w^m): 11 complex multiplications instead of 11
+// 16-byte loads per thread and pass.  The vector-memory path, not the fp64 pipe, is what the headline kernel runs out of
+// (measured: dropping those loads -6.4 %, halving the kernel's MFMAs -3 %); a generated twiddle is off by 2-4e-16.
+template <int LOG2M, int R, int NS, int DIR, int MODE, bool LAST, int PF = 0, int NSN = 1, bool TWGEN = false>
 __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds,
                                          const double2 (&wcur)[15], double2 (&wnext)[15], const double2 *__restrict__ twn)
 {
@@ -239,11 +246,29 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
       c64 b[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) b[r] = v[t + NB * r];
-      if (NS > 1) {
+      if (NS > 1 && TWGEN && R == 16) {
+        const int k = (tid + t * T) & (NS - 1);
+        c64 w[16];
+#pragma unroll
+        for (int r = 1; r < 16; r <<= 1) {
+          const double2 q = (PF > 0 && NB == 1) ? wcur[r - 1] : tw[(r - 1) * NS + k];
+          w[r] = {q.x, q.y};
+        }
+        w[3] = cmul(w[1], w[2]);
+        w[5] = cmul(w[4], w[1]);
+        w[6] = cmul(w[4], w[2]);
+        w[7] = cmul(w[4], w[3]);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) w[8 + m] = cmul(w[8], w[m]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) b[r] = DIR > 0 ? cmul(b[r], w[r]) : cmulc(b[r], w[r]);
+      } else if (NS > 1) {
         const int k = (tid + t * T) & (NS - 1);
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-          const double2 w = (PF > 0 && r - 1 < PF && NB == 1) ? wcur[r - 1] : tw[(r - 1) * NS + k];
+          // RSMP_EXP_TWLOAD (timing experiment only, WRONG results): load the twiddles of r = 1, 2, 4, 8 only
+          const int rr = (RSMP_EXP_TWLOAD && (r & (r - 1))) ? 1 : r;
+          const double2 w = (PF > 0 && rr - 1 < PF && NB == 1) ? wcur[rr - 1] : tw[(rr - 1) * NS + k];
           b[r] = DIR > 0 ? cmul(b[r], c64{w.x, w.y}) : cmulc(b[r], c64{w.x, w.y});
         }
       }
@@ -256,7 +281,8 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
     if (PF > 0 && active) {
       const int kn = tid & (NSN - 1);
 #pragma unroll
-      for (int r = 1; r <= PF; ++r) wnext[r - 1] = twn[(r - 1) * NSN + kn];
+      for (int r = 1; r <= (TWGEN ? 8 : PF); ++r)
+        if (!((RSMP_EXP_TWLOAD || TWGEN) && (r & (r - 1)))) wnext[r - 1] = twn[(r - 1) * NSN + kn];
     }
     int pos[16];
 #pragma unroll
@@ -271,18 +297,18 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 
 // Full transform.  `tw` points at this size's table (fft_twiddle_count(LOG2M) entries).
 // PF = number of twiddles (of 15) per pass that are prefetched ahead of the preceding exchange (registers: 4 each).
-template <int LOG2M, int DIR, int MODE, int PF = 0>
+template <int LOG2M, int DIR, int MODE, int PF = 0, bool TWGEN = false>
 __device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int R0 = fft_first_radix(LOG2M), NP = fft_num_passes(LOG2M);
   double2 wa[15], wb[15];
-  fft_pass<LOG2M, R0, 1, DIR, MODE, NP == 1, NP >= 2 ? PF : 0, R0>(v, tid, active, tw, lds, wa, wa, tw);
+  fft_pass<LOG2M, R0, 1, DIR, MODE, NP == 1, NP >= 2 ? PF : 0, R0, TWGEN>(v, tid, active, tw, lds, wa, wa, tw);
   if constexpr (NP >= 2)
-    fft_pass<LOG2M, 16, R0, DIR, MODE, NP == 2, NP >= 3 ? PF : 0, R0 * 16>(v, tid, active, tw, lds, wa, wb, tw + 15 * R0);
+    fft_pass<LOG2M, 16, R0, DIR, MODE, NP == 2, NP >= 3 ? PF : 0, R0 * 16, TWGEN>(v, tid, active, tw, lds, wa, wb, tw + 15 * R0);
   if constexpr (NP >= 3)
-    fft_pass<LOG2M, 16, R0 * 16, DIR, MODE, NP == 3, NP >= 4 ? PF : 0, R0 * 256>(v, tid, active, tw + 15 * R0, lds, wb, wa,
-                                                                                  tw + 15 * R0 * 17);
-  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4, 0, 1>(v, tid, active, tw + 15 * R0 * 17, lds, wa, wb, tw);
+    fft_pass<LOG2M, 16, R0 * 16, DIR, MODE, NP == 3, NP >= 4 ? PF : 0, R0 * 256, TWGEN>(v, tid, active, tw + 15 * R0, lds, wb, wa,
+                                                                                         tw + 15 * R0 * 17);
+  if constexpr (NP >= 4) fft_pass<LOG2M, 16, R0 * 256, DIR, MODE, NP == 4, 0, 1, TWGEN>(v, tid, active, tw + 15 * R0 * 17, lds, wa, wb, tw);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -304,7 +330,7 @@ constexpr int fft8_twiddle_count(int log2m)
 }
 constexpr int fft8_lds_doubles(int log2m) { return 2 * ((1 << log2m) + (1 << log2m) / 8); } // first exchange padded
 
-template <int LOG2M, int R, int NS, int DIR, bool LAST>
+template <int LOG2M, int R, int NS, int DIR, bool LAST, bool TWGEN = false>
 __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds, bool active = true)
 {
   constexpr int T8 = (1 << LOG2M) / 8, NB = 8 / R;
@@ -314,11 +340,28 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
     c64 b[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) b[r] = u[t + NB * r];
-    if (NS > 1) {
+    if (NS > 1 && TWGEN && R >= 4) { // w^1, w^2 (, w^4) loaded, the rest multiplied up (see fft_pass)
+      const int k = (tid + t * T8) & (NS - 1);
+      c64 w[8];
+#pragma unroll
+      for (int r = 1; r < R; r <<= 1) {
+        const double2 q = tw[(r - 1) * NS + k];
+        w[r] = {q.x, q.y};
+      }
+      w[3] = cmul(w[1], w[2]);
+      if (R == 8) {
+        w[5] = cmul(w[4], w[1]);
+        w[6] = cmul(w[4], w[2]);
+        w[7] = cmul(w[4], w[3]);
+      }
+#pragma unroll
+      for (int r = 1; r < R; ++r) b[r] = DIR > 0 ? cmul(b[r], w[r]) : cmulc(b[r], w[r]);
+    } else if (NS > 1) {
       const int k = (tid + t * T8) & (NS - 1);
 #pragma unroll
       for (int r = 1; r < R; ++r) {
-        const double2 w = tw[(r - 1) * NS + k];
+        const int rr = (RSMP_EXP_TWLOAD && (r & (r - 1))) ? 1 : r;
+        const double2 w = tw[(rr - 1) * NS + k];
         b[r] = DIR > 0 ? cmul(b[r], c64{w.x, w.y}) : cmulc(b[r], c64{w.x, w.y});
       }
     }
@@ -351,26 +394,26 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
 }
 
 // `active`: threads that hold points (tid < M/8); every thread of the workgroup must call (barriers)
-template <int LOG2M, int DIR>
+template <int LOG2M, int DIR, bool TWGEN = false>
 __device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M);
   static_assert(NP >= 2 && NP <= 5, "fft8_regs: 64 <= M <= 8192");
-  fft8_pass<LOG2M, 8, 1, DIR, false>(u, tid, tw, lds, active);
-  if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true>(u, tid, tw, lds, active);
-  if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false>(u, tid, tw, lds, active);
-  if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true>(u, tid, tw + 7 * 8, lds, active);
-  if constexpr (NP >= 4) fft8_pass<LOG2M, 8, 64, DIR, false>(u, tid, tw + 7 * 8, lds, active);
-  if constexpr (NP == 4) fft8_pass<LOG2M, RL, 512, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
+  fft8_pass<LOG2M, 8, 1, DIR, false, TWGEN>(u, tid, tw, lds, active);
+  if constexpr (NP == 2) fft8_pass<LOG2M, RL, 8, DIR, true, TWGEN>(u, tid, tw, lds, active);
+  if constexpr (NP >= 3) fft8_pass<LOG2M, 8, 8, DIR, false, TWGEN>(u, tid, tw, lds, active);
+  if constexpr (NP == 3) fft8_pass<LOG2M, RL, 64, DIR, true, TWGEN>(u, tid, tw + 7 * 8, lds, active);
+  if constexpr (NP >= 4) fft8_pass<LOG2M, 8, 64, DIR, false, TWGEN>(u, tid, tw + 7 * 8, lds, active);
+  if constexpr (NP == 4) fft8_pass<LOG2M, RL, 512, DIR, true, TWGEN>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
   if constexpr (NP == 5) {
-    fft8_pass<LOG2M, 8, 512, DIR, false>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
-    fft8_pass<LOG2M, RL, 4096, DIR, true>(u, tid, tw + 7 * 8 + 7 * 64 + 7 * 512, lds, active);
+    fft8_pass<LOG2M, 8, 512, DIR, false, TWGEN>(u, tid, tw + 7 * 8 + 7 * 64, lds, active);
+    fft8_pass<LOG2M, RL, 4096, DIR, true, TWGEN>(u, tid, tw + 7 * 8 + 7 * 64 + 7 * 512, lds, active);
   }
 }
-template <int LOG2M, int DIR>
+template <int LOG2M, int DIR, bool TWGEN = false>
 __device__ __forceinline__ void fft8_regs(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
 {
-  fft8_regs_masked<LOG2M, DIR>(u, tid, true, tw, lds);
+  fft8_regs_masked<LOG2M, DIR, TWGEN>(u, tid, true, tw, lds);
 }
 
 } // namespace rsmp

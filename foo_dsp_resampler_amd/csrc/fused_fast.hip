@@ -28,6 +28,16 @@
 #define RSMP_FAST_FWD8 1
 #endif
 // wave priority by phase: 1 = FFT phases above the polyphase phase, 2 = the other way round (experiments)
+// twiddles multiplied up from w^1, w^2, w^4, w^8 instead of loaded (fft_device.hpp, TWGEN)
+#ifndef RSMP_TWGEN
+#define RSMP_TWGEN 1
+#endif
+#ifndef RSMP_EXP_HALFMFMA
+#define RSMP_EXP_HALFMFMA 0
+#endif
+#ifndef RSMP_EXP_LINEAR
+#define RSMP_EXP_LINEAR 0
+#endif
 #ifndef RSMP_PRIO
 #define RSMP_PRIO 0
 #endif
@@ -41,6 +51,21 @@
 namespace rsmp {
 
 namespace {
+// G is read once per workgroup (64 KB, twice the vector L1): RSMP_G_NT = 1 loads it non-temporally so that it does not evict
+// the twiddle rows and coefficient tiles the workgroups of a CU share
+#ifndef RSMP_G_NT
+#define RSMP_G_NT 0
+#endif
+typedef double rsmp_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_g(const double2 *p)
+{
+#if RSMP_G_NT
+  const rsmp_d2v q = __builtin_nontemporal_load(reinterpret_cast<const rsmp_d2v *>(p));
+  return make_double2(q.x, q.y);
+#else
+  return *p;
+#endif
+}
 constexpr int kPad = 32;
 constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 } // namespace
@@ -110,19 +135,19 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   if constexpr (FWD8) {
     double2 g[16]; // in flight during the whole forward transform
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
-    fft8_regs<LOG2P, -1>(u8, tid, a.d.tw_fwd8, lds);
+    for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + s * T);
+    fft8_regs<LOG2P, -1, RSMP_TWGEN != 0>(u8, tid, a.d.tw_fwd8, lds);
     RSMP_STAMP(1)
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = cmul(u8[s & 7], c64{g[s].x, g[s].y});
     __syncthreads(); // the inverse transform's exchange reuses the LDS the forward one just read
   } else {
-  fft_regs<LOG2P, -1, LOG2P == LOG2N ? 2 : 0, RSMP_PFW>(v, tid, fwd_active, a.d.tw_fwd, lds);
+  fft_regs<LOG2P, -1, LOG2P == LOG2N ? 2 : 0, RSMP_PFW, RSMP_TWGEN != 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
   RSMP_STAMP(1)
   if constexpr (LOG2P < LOG2N) {
     double2 g[16]; // issued before the exchange so the L2 latency overlaps it
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
+    for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + s * T);
     double2 *l2 = reinterpret_cast<double2 *>(lds);
     // Z[tid + s*T] = Zp[tid + (s & 7) * T]: a forward thread (tid < TF) already holds those in its even slots; its odd
     // slots are what thread tid + TF needs
@@ -148,13 +173,13 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const double2 g = Gp[tid + s * T];
+      const double2 g = load_g(Gp + tid + s * T);
       v[s] = cmul(v[s], c64{g.x, g.y});
     }
   }
   }
   RSMP_STAMP(2)
-  fft_regs<LOG2N, +1, 2, RSMP_PFI>(v, tid, true, a.d.tw_inv, lds);
+  fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
   RSMP_STAMP(3)
 
   // ---------------------------------------------------------------- stage-1 samples -> LDS (round A) and seam ring
@@ -232,7 +257,11 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 
     double2 x0[KS], x1[KS];
     auto fill = [&](double2 (&x)[KS], int q, int cstep) {
+#if RSMP_EXP_LINEAR // timing experiment only (WRONG results): lane-linear, conflict-free window addresses
+      const int li = li_lo + 32 + lane + ((cstep * 64 + (q & 63)) & 1023);
+#else
       const int li = max(li_lo, min(li_hi, lane_li + q + cstep * step4));
+#endif
       const double2 *xp = xs + li;
 #pragma unroll
       for (int s = 0; s < KS; ++s) x[s] = xp[4 * s];
@@ -251,10 +280,14 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       fill(xn, switch_group ? qn : qc, left > 1 ? cnext : c); // after the last tile: a harmless re-read
       double accA = 0.0, accB = 0.0;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int s = 0; s < (RSMP_EXP_HALFMFMA ? 3 : KS); ++s) { // RSMP_EXP_HALFMFMA: timing experiment only (WRONG results)
         accA = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].x, accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].y, accB, 0, 0, 0);
       }
+#if RSMP_EXP_HALFMFMA
+#pragma unroll
+      for (int s = 3; s < KS; ++s) { accA += xc[s].x * 1e-30; accB += cc[s] * 1e-30 + xc[s].y * 1e-30; } // keep the loads alive
+#endif
       const int ib = lane_ib + 16 * g + c * pl4;
       if (ib >= 0 && ib < cnt && 16 * g + rloc < pl)
         *reinterpret_cast<float2 *>(obytes + (unsigned)(ib * frame_bytes)) = make_float2((float)accA, (float)accB);
