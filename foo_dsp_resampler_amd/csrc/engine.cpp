@@ -322,6 +322,26 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         void *dm = nullptr;
         if ((rc = upload(am.data(), am.size() * sizeof(double), &dm)) != kOk) return rc;
         fu.cfm = static_cast<double *>(dm);
+        { // the same tiles, two k-steps per 16-byte element (half the load instructions in the lean kernel)
+          const int KSP = (KS + 1) / 2;
+          std::vector<double2> am2(size_t(NGRP) * KSP * 64, make_double2(0.0, 0.0));
+          for (int g = 0; g < NGRP; ++g)
+            for (int s = 0; s < KS; ++s)
+              for (int lane = 0; lane < 64; ++lane) {
+                double2 &d = am2[(size_t(g) * KSP + s / 2) * 64 + lane];
+                (s & 1 ? d.y : d.x) = am[(size_t(g) * KS + s) * 64 + lane];
+              }
+          if (KS & 1) // the spare half of the last element carries the lane's window start (as qtab: block bq = (lane >> 2) & 3)
+            for (int g = 0; g < NGRP; ++g)
+              for (int lane = 0; lane < 64; ++lane) {
+                int rb = 16 * g + 4 * ((lane >> 2) & 3);
+                if (rb >= p.L) rb = 0;
+                am2[(size_t(g) * KSP + KSP - 1) * 64 + lane].y = double((at0 + rb * pstep) / p.L);
+              }
+          void *d2 = nullptr;
+          if ((rc = upload(am2.data(), am2.size() * sizeof(double2), &d2)) != kOk) return rc;
+          fu.cfm2 = static_cast<double2 *>(d2);
+        }
         fu.NGRP = NGRP;
         fu.KS = KS;
         fu.qb_max = qb_max;
@@ -580,6 +600,7 @@ Engine::~Engine()
     if (f.cft) (void)hipFree(f.cft);
     if (f.cfm) (void)hipFree(f.cfm);
     if (f.qtab) (void)hipFree(f.qtab);
+    if (f.cfm2) (void)hipFree(f.cfm2);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
   for (BigDft &b : big_) {
@@ -853,6 +874,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           fa.kper = fu.kper;
           fa.cfm = fu.cfm;
           fa.qtab = fu.qtab;
+          fa.cfm2 = fu.cfm2;
           fa.NGRP = fu.NGRP;
           fa.KS = fu.KS;
           fa.dbg = dbg_;

@@ -126,7 +126,7 @@ private:
   std::vector<BigDft> big_;         // indexed by stage
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0;
-                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0, qb_min = 0; int *qtab = nullptr;
+                double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0, qb_min = 0; int *qtab = nullptr; double2 *cfm2 = nullptr;
                 FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   // standalone matrix-pipe polyphase stage (polymf.hip), indexed by the poly stage

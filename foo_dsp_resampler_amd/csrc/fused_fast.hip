@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   char *const obytes = reinterpret_cast<char *>(io.out + strm * io.out_stream_stride + (a.out_offset2 + fb.i_lo - io.out_abs0) * io.nch + 2 * pin);
   const int rloc = 4 * bq + hi; // this lane's output residue within a 16-residue group
   const int ngrp = a.NGRP;
-  const double *const cfm_lane = a.cfm + lane;
+  const double2 *const cfm_lane = a.cfm2 + lane;
   const int *const qtab_lane = a.qtab + bq;
 
   auto poly_round = [&](int kb, int ke, const double2 *xs, int li_lo, int li_hi) {
@@ -247,10 +247,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     double cc[KS], cn[KS]; // coefficient tiles: current group, next group (in flight)
     int qc, qn = 0;
     auto load_tile = [&](int gg, double (&c_)[KS], int &q_) {
-      const double *cp = cfm_lane + gg * (KS * 64); // uniform offset
+      constexpr int KSP = (KS + 1) / 2;
+      const double2 *cp = cfm_lane + gg * (KSP * 64); // uniform offset; two k-steps per 16-byte load
 #pragma unroll
-      for (int s = 0; s < KS; ++s) c_[s] = cp[s * 64];
-      q_ = qtab_lane[gg * 4];
+      for (int s2 = 0; s2 < KSP; ++s2) {
+        const double2 d = cp[s2 * 64];
+        c_[2 * s2] = d.x;
+        if (2 * s2 + 1 < KS) c_[2 * s2 + 1] = d.y;
+        else q_ = (int)d.y; // odd KS: the spare half carries the window start
+      }
+      if (!(KS & 1)) q_ = qtab_lane[gg * 4];
     };
     load_tile(g, cc, qc);
     if (g < g_last) load_tile(g + 1, cn, qn);

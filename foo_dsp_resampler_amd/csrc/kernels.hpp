@@ -152,6 +152,7 @@ struct FusedArgs {
   unsigned long long *stamps; // RSMP_STAMPS: per-phase cycle sums [8] (null in production)
   const FusedBlock *blk; // [nblocks] in HBM, written by fused_prep_kernel ahead of the launch
   const int *qtab;       // matrix-pipe variant: window start (at0 + rb*step)/polyL of every 4-residue block rb = 4*i, [NGRP*4]
+  const double2 *cfm2;   // the same A operands two k-steps per 16-byte element: [group][(KS + 1) / 2][lane] (lean kernel)
 };
 
 // Lean fast path of the matrix-pipe variant (fused_fast.hip): both ends are plain interleaved float frames in one buffer each
