@@ -139,6 +139,13 @@ constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) 
 //         padding): same LDS traffic as mode 0, two more barriers, half the footprint.
 // RSMP_EXP_NOBAR (timing experiments only, results are WRONG): exchanges after the first one of a transform run without
 // their workgroup barriers -- an upper bound for what wave-local exchanges could save.
+// default of the TWGEN template parameter of fft_regs / fft8_regs (every kernel that does not say otherwise)
+#ifndef RSMP_TWGEN_DEFAULT
+#define RSMP_TWGEN_DEFAULT 1
+#endif
+#ifndef RSMP_TWGEN_SQ
+#define RSMP_TWGEN_SQ 0
+#endif
 #ifndef RSMP_EXP_TWLOAD
 #define RSMP_EXP_TWLOAD 0
 #endif
@@ -251,6 +258,10 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
         c64 w[16];
 #pragma unroll
         for (int r = 1; r < 16; r <<= 1) {
+          if (RSMP_TWGEN_SQ && r > 1) { // experiment: w^2, w^4, w^8 by squaring (one load per butterfly)
+            w[r] = cmul(w[r >> 1], w[r >> 1]);
+            continue;
+          }
           const double2 q = (PF > 0 && NB == 1) ? wcur[r - 1] : tw[(r - 1) * NS + k];
           w[r] = {q.x, q.y};
         }
@@ -282,7 +293,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
       const int kn = tid & (NSN - 1);
 #pragma unroll
       for (int r = 1; r <= (TWGEN ? 8 : PF); ++r)
-        if (!((RSMP_EXP_TWLOAD || TWGEN) && (r & (r - 1)))) wnext[r - 1] = twn[(r - 1) * NSN + kn];
+        if (!((RSMP_EXP_TWLOAD || TWGEN) && (r & (r - 1))) && !(TWGEN && RSMP_TWGEN_SQ && r > 1)) wnext[r - 1] = twn[(r - 1) * NSN + kn];
     }
     int pos[16];
 #pragma unroll
@@ -297,7 +308,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 
 // Full transform.  `tw` points at this size's table (fft_twiddle_count(LOG2M) entries).
 // PF = number of twiddles (of 15) per pass that are prefetched ahead of the preceding exchange (registers: 4 each).
-template <int LOG2M, int DIR, int MODE, int PF = 0, bool TWGEN = false>
+template <int LOG2M, int DIR, int MODE, int PF = 0, bool TWGEN = (RSMP_TWGEN_DEFAULT != 0)>
 __device__ __forceinline__ void fft_regs(c64 (&v)[16], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int R0 = fft_first_radix(LOG2M), NP = fft_num_passes(LOG2M);
@@ -345,6 +356,10 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
       c64 w[8];
 #pragma unroll
       for (int r = 1; r < R; r <<= 1) {
+        if (RSMP_TWGEN_SQ && r > 1) {
+          w[r] = cmul(w[r >> 1], w[r >> 1]);
+          continue;
+        }
         const double2 q = tw[(r - 1) * NS + k];
         w[r] = {q.x, q.y};
       }
@@ -394,7 +409,7 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
 }
 
 // `active`: threads that hold points (tid < M/8); every thread of the workgroup must call (barriers)
-template <int LOG2M, int DIR, bool TWGEN = false>
+template <int LOG2M, int DIR, bool TWGEN = (RSMP_TWGEN_DEFAULT != 0)>
 __device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool active, const double2 *__restrict__ tw, double *lds)
 {
   constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M);
@@ -410,7 +425,7 @@ __device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool acti
     fft8_pass<LOG2M, RL, 4096, DIR, true, TWGEN>(u, tid, tw + 7 * 8 + 7 * 64 + 7 * 512, lds, active);
   }
 }
-template <int LOG2M, int DIR, bool TWGEN = false>
+template <int LOG2M, int DIR, bool TWGEN = (RSMP_TWGEN_DEFAULT != 0)>
 __device__ __forceinline__ void fft8_regs(c64 (&u)[8], int tid, const double2 *__restrict__ tw, double *lds)
 {
   fft8_regs_masked<LOG2M, DIR, TWGEN>(u, tid, true, tw, lds);
