@@ -265,14 +265,23 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
           const double2 q = (PF > 0 && NB == 1) ? wcur[r - 1] : tw[(r - 1) * NS + k];
           w[r] = {q.x, q.y};
         }
+        // every twiddle is applied as soon as it exists, so that at most w^1..w^8 are live together (32 registers, not 60:
+        // this is what removes most of the spills of the 128-VGPR kernels)
+        auto apply = [&](int r, c64 wr) { b[r] = DIR > 0 ? cmul(b[r], wr) : cmulc(b[r], wr); };
+        apply(1, w[1]);
+        apply(2, w[2]);
+        apply(4, w[4]);
         w[3] = cmul(w[1], w[2]);
+        apply(3, w[3]);
         w[5] = cmul(w[4], w[1]);
+        apply(5, w[5]);
         w[6] = cmul(w[4], w[2]);
+        apply(6, w[6]);
         w[7] = cmul(w[4], w[3]);
+        apply(7, w[7]);
+        apply(8, w[8]);
 #pragma unroll
-        for (int m = 1; m < 8; ++m) w[8 + m] = cmul(w[8], w[m]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) b[r] = DIR > 0 ? cmul(b[r], w[r]) : cmulc(b[r], w[r]);
+        for (int m = 1; m < 8; ++m) apply(8 + m, cmul(w[8], w[m]));
       } else if (NS > 1) {
         const int k = (tid + t * T) & (NS - 1);
 #pragma unroll
