@@ -195,6 +195,23 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         if ((rc = upload(G.data(), G.size() * sizeof(double2), &d)) != kOk) return rc;
         d_G_[sp.filt] = static_cast<double2 *>(d);
       }
+      if (!big && !d_Gr_[sp.filt] && sp.step == 1 && fdomain_up(sp.L) && dftx_supported(log2n, log2p, log2nd)) {
+        // G_r = DFT_P(L * h_placed[L j + r]) / P, r < L: the block's L polyphase components (dftx.hip)
+        const int Lx = sp.L, Px = Ng / Lx;
+        std::vector<double2> Gr(size_t(Lx) * Px);
+        for (int r = 0; r < Lx; ++r) {
+          std::vector<cplx> g(Px);
+          for (int i2 = 0; i2 < f.num_taps; ++i2) {
+            const int m = (i2 + Ng - f.num_taps + 1) & (Ng - 1);
+            if (m % Lx == r) g[m / Lx] = f.taps[i2] * sp.L;
+          }
+          fft_inplace(g, -1);
+          for (int k = 0; k < Px; ++k) Gr[size_t(r) * Px + k] = make_double2(g[k].real() / Px, g[k].imag() / Px);
+        }
+        void *d = nullptr;
+        if ((rc = upload(Gr.data(), Gr.size() * sizeof(double2), &d)) != kOk) return rc;
+        d_Gr_[sp.filt] = static_cast<double2 *>(d);
+      }
       if (big) {
         BigDft &bg = big_[i];
         bg.on = true;
@@ -575,6 +592,7 @@ Engine::~Engine()
   free_garbage();
   for (Ring &r : rings_) if (r.buf) (void)hipFree(r.buf);
   for (double2 *&g : d_G_) if (g) (void)hipFree(g);
+  for (double2 *&g : d_Gr_) if (g) (void)hipFree(g);
   if (d_poly_) (void)hipFree(d_poly_);
   for (double2 *&t : d_tw_) if (t) (void)hipFree(t);
   for (double2 *&t : d_tw8_) if (t) (void)hipFree(t);
@@ -785,6 +803,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         const int log2n = ilog2(Ng);
         DftArgs a;
         a.G = d_G_[sp.filt];
+        a.Gr = d_Gr_[sp.filt];
         const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
         const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
         const bool big = big_[i].on;
@@ -832,6 +851,13 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pend_args = a;
           pend_log2n = log2n;
           pend_log2p = log2p;
+        } else if (a.Gr && sp.step == 1 && fdomain_up(L) && dftx_supported(log2n, log2p, log2nd)) {
+          const int pi = prof_begin(true);
+          const char *kn = nullptr;
+          HIP_TRY(launch_dftx(log2n, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                              dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+          prof_name(pi, kn);
+          prof_end(pi);
         } else {
         const int pi = prof_begin(true);
         const char *kn = nullptr;

@@ -117,6 +117,7 @@ private:
   std::vector<void *> garbage_;
   // device tables
   double2 *d_G_[2] = {nullptr, nullptr};
+  double2 *d_Gr_[2] = {nullptr, nullptr}; // dftx_kernel: spectra of the polyphase components of the same filters
   double *d_poly_ = nullptr;
   double2 *d_tw_[20] = {};
   double2 *d_tw8_[20] = {}; // 8-points-per-thread plans (fft8_regs)

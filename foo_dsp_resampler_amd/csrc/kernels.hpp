@@ -33,6 +33,7 @@ struct F64View {
 
 struct DftArgs {
   const double2 *G;      // N entries: DFT_N(L * h_placed) / N, natural order, e^{-i} convention
+  const double2 *Gr;     // dftx_kernel: [L][N/L] spectra of the filter's polyphase components, DFT_P(L * h_placed[L j + r]) / P
   const double2 *tw_fwd; // twiddle table for the forward size P
   const double2 *tw_inv; // twiddle table for the inverse size Nd
   const double2 *tw_fwd8; // forward size P, 8-points-per-thread plan (fft8_regs)
@@ -197,6 +198,10 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
 hipError_t launch_half(bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
                        const F64View &dd, const HalfArgs &a, hipStream_t st, const char **kname = nullptr);
 bool dft_shape_supported(int log2n, int log2p, int log2nd);
+// x4 upsampling on 8192-point blocks as four 2048-point component transforms (dftx.hip); needs DftArgs::Gr
+bool dftx_supported(int log2n, int log2p, int log2nd);
+hipError_t launch_dftx(int log2n, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,
+                       const F64View &dd, const DftArgs &a, hipStream_t st, const char **kname = nullptr);
 hipError_t launch_fused(int log2n, int log2p, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd,
                         const F32View &df, const F64View &dd, const FusedArgs &a, hipStream_t st, const char **kname = nullptr);
 // seam_kernel: the outputs whose window straddles two blocks; launch after launch_fused on the same stream

@@ -20,6 +20,8 @@ CASES = [
     ("192k->44.1k 2ch (h12+dft+poly)", 192000, 44100, 2, 128, {}),
     ("44100->48001 2ch (vpoly3)", 44100, 48001, 2, 128, {}),
     ("44.1k->48k 2ch Normal", 44100, 48000, 2, 256, {"quality": 1}),
+    ("48k->192k 2ch (dft x4)", 48000, 192000, 2, 256, {}),
+    ("44.1k->176.4k 8ch (dft x4)", 44100, 176400, 8, 32, {}),
 ]
 
 
