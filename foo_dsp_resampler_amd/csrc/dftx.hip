@@ -27,6 +27,10 @@
 #include <atomic>
 #include <cstdlib>
 
+#ifndef RSMP_DFTX_SKIP
+#define RSMP_DFTX_SKIP 0 // timing experiments only (WRONG results): 1 = no stores of the first component pair, 2 = of the last
+#endif
+
 namespace rsmp {
 
 namespace {
@@ -213,7 +217,9 @@ template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kern
             f[j] = stg[tid + jj[j] * 256];
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) *reinterpret_cast<float2 *>(ob8 + (unsigned)(jj[j] * (128 * LL)) * fbytes) = f[j];
+          for (int j = 0; j < 8; ++j)
+            if (!(RSMP_DFTX_SKIP == 1 && r == 1) && !(RSMP_DFTX_SKIP == 2 && r == LL - 1))
+              *reinterpret_cast<float2 *>(ob8 + (unsigned)(jj[j] * (128 * LL)) * fbytes) = f[j];
         }
       }
     } else if ((GENERIC && so.kind == 2) || OKIND == 2) { // planar fp64 rings, contiguous

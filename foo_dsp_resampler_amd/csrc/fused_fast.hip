@@ -35,6 +35,10 @@
 #ifndef RSMP_EXP_HALFMFMA
 #define RSMP_EXP_HALFMFMA 0
 #endif
+// output stores as raw buffer stores with the range check done by the buffer descriptor (no per-tile compare / branch)
+#ifndef RSMP_BUFSTORE
+#define RSMP_BUFSTORE 1
+#endif
 #ifndef RSMP_EXP_LINEAR
 #define RSMP_EXP_LINEAR 0
 #endif
@@ -57,6 +61,7 @@ namespace {
 #define RSMP_G_NT 0
 #endif
 typedef double rsmp_d2v __attribute__((ext_vector_type(2)));
+typedef unsigned int rsmp_v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 load_g(const double2 *p)
 {
 #if RSMP_G_NT
@@ -242,6 +247,11 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     const int lane_li = fb.base_li + hi + (kb + jq) * step; // window start = lane_li + q(group, block) + c * 4 * step
     const int lane_ib = (kb + jq) * pl + rloc - fb.irel_lo; // output index relative to i_lo = lane_ib + 16 g + c * 4 * pl
     const int cnt = hi_bound - fb.irel_lo;
+#if RSMP_BUFSTORE
+    // raw buffer over this round's outputs [0, cnt) of the block: frame ib at byte ib * frame_bytes, 8 bytes of it are ours
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(obytes, 0, cnt > 0 ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
+#endif
     const int step4 = 4 * step, pl4 = 4 * pl;
 
     double cc[KS], cn[KS]; // coefficient tiles: current group, next group (in flight)
@@ -295,8 +305,19 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       for (int s = 3; s < KS; ++s) { accA += xc[s].x * 1e-30; accB += cc[s] * 1e-30 + xc[s].y * 1e-30; } // keep the loads alive
 #endif
       const int ib = lane_ib + 16 * g + c * pl4;
+#if RSMP_BUFSTORE
+      {
+        // one unconditional buffer store per tile: outputs in front of the block (ib < 0 wraps to a huge offset) and behind
+        // the round's last one fail the descriptor's range check and are dropped by the hardware; only the residue test of
+        // the last (partial) group needs a select
+        const unsigned off = (16 * g + rloc < pl) ? (unsigned)(ib * frame_bytes) : 0xffffffffu;
+        const rsmp_v2u d = {__float_as_uint((float)accA), __float_as_uint((float)accB)};
+        __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (int)off, 0, 0);
+      }
+#else
       if (ib >= 0 && ib < cnt && 16 * g + rloc < pl)
         *reinterpret_cast<float2 *>(obytes + (unsigned)(ib * frame_bytes)) = make_float2((float)accA, (float)accB);
+#endif
       if (switch_group) { // uniform
 #pragma unroll
         for (int s = 0; s < KS; ++s) cc[s] = cn[s];
