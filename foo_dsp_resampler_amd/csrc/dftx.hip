@@ -118,16 +118,17 @@ template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kern
 
   const int tid = threadIdx.x;
   int bl, pair;
-  if (!item_map(blockIdx.x, a.nblocks, (a.C + 1) >> 1, a.hp, bl, pair)) return; // uniform
+  if (!item_map(blockIdx.x, a.nblocks, pair_count(a.C, a.nchs), a.hp, bl, pair)) return; // uniform
   const long long B = a.B0 + bl;
-  const int ca = 2 * pair, cb = ca + 1;
-  const bool hasb = cb < a.C;
+  const PairCh pc = pair_channels(pair, a.C, a.nchs);
+  const int ca = pc.ca, cb = pc.cb;
+  const bool hasb = pc.hasb;
 
   // ---- the block's P inputs (dft_filter.h:88: the frequency-domain branch reads N/L inputs from the block start)
   c64 x[8];
   {
     const long long base = B * a.q;
-    const PairSpan sp = pair_span(in, pair, hasb, base, P);
+    const PairSpan sp = pair_span(in, pair, hasb, base, P, ca);
     if (sp.kind == 1) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -166,7 +167,7 @@ template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kern
   // ---- the L components, staged and stored two at a time
   const long long o0 = B * a.Vout;
   const bool whole = o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi;
-  const PairSpan so = whole ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+  const PairSpan so = whole ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
   if (!GENERIC && so.kind != OKIND) __builtin_trap(); // the host's range check and pair_span disagree
   const double2 *__restrict__ Gt = a.Gr + tid;
   float2 keep[8];
@@ -269,7 +270,7 @@ template <int LL, int OKIND> static hipError_t launch_dftx_run(const AnyView &in
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
   }
-  dim3 grid(item_grid(a.nblocks, (a.C + 1) / 2, a.hp)), block(256);
+  dim3 grid(item_grid(a.nblocks, pair_count(a.C, a.nchs), a.hp)), block(256);
   hipLaunchKernelGGL((dftx_kernel<LL, OKIND>), grid, block, kXLdsBytes, st, in, out, a);
   return hipGetLastError();
 }

@@ -225,7 +225,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         if ((rc = upload(tw.data(), tw.size() * sizeof(double2), &d)) != kOk) return rc;
         bg.twN = static_cast<double2 *>(d);
         // (block, pair) items in flight per round of the three launches: at most 256 MB per workspace
-        const int npairs = (C_ + 1) / 2;
+        const int npairs = pair_count(C_, pair_nchs());
         bg.ws_items = int(std::max<long long>(1, std::min<long long>((256LL << 20) / (16LL * Ng), std::max(4 * npairs, 16))));
         ALLOC_TRY(&bg.w1, size_t(bg.ws_items) * (size_t(1) << log2p) * sizeof(double2));
         ALLOC_TRY(&bg.w2, size_t(bg.ws_items) * (size_t(1) << log2nd) * sizeof(double2));
@@ -824,6 +824,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.q = (Vg - sp.remL0 + L - 1) / L;
         a.M = sp.step > 1 ? sp.step : 1;
         a.hp = 0; // set by the launchers (frame_pairs)
+        a.nchs = pair_nchs();
         a.in_limit = 0x7fffffffffffffffLL;
         a.clip_lo = -0x7fffffffffffffffLL;
         a.clip_hi = 0x7fffffffffffffffLL;
@@ -1037,6 +1038,7 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           a.polyL = sp.L;
           a.step = int(step);
           a.NGRP = pm.NGRP;
+          a.nchs = pair_nchs();
           const int pi = prof_begin(false);
           const char *kn = nullptr;
           HIP_TRY(launch_polymf(pm.KS, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),

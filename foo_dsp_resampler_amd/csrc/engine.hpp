@@ -38,6 +38,9 @@ public:
   const ChainPlan &plan() const { return plan_; }
   int nch() const { return nch_; }
   int nstreams() const { return S_; }
+  // batch handles with an odd channel count per stream: channel pairs stay inside a stream (pair_channels), so that every
+  // stream gets the bits its own handle would give
+  int pair_nchs() const { return (S_ > 1 && (nch_ & 1)) ? nch_ : 0; }
   size_t isamp_max() const { return plan_.isamp_max; }
   size_t available() const { return size_t(book_.wr.back() - book_.rd.back()); }
 

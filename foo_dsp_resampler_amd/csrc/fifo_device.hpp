@@ -65,6 +65,30 @@ __device__ __forceinline__ void fifo_put(const ChanRef &r, long long a, double v
 }
 
 
+// Channel pair -> channels.  nchs = 0: pairs run over all C channels of the handle (2p, 2p+1; the last one may be single).
+// nchs > 0 (batch handles with an odd channel count per stream): pairs never straddle two streams -- every stream has
+// (nchs + 1) / 2 of them and its last channel rides alone with a zero imaginary part, exactly as in a one-stream handle,
+// so the bits a stream gets do not depend on its neighbours in the batch.
+struct PairCh {
+  int ca, cb;
+  bool hasb;
+};
+__device__ __forceinline__ PairCh pair_channels(int pair, int C, int nchs)
+{
+  PairCh r;
+  if (nchs <= 0) {
+    r.ca = 2 * pair;
+    r.cb = r.ca + 1;
+    r.hasb = r.cb < C;
+  } else {
+    const int pps = (nchs + 1) >> 1, strm = pair / pps, pin = pair - strm * pps;
+    r.ca = strm * nchs + 2 * pin;
+    r.cb = r.ca + 1;
+    r.hasb = 2 * pin + 1 < nchs;
+  }
+  return r;
+}
+
 // Direct addressing of `len` consecutive samples of channel pair (2*pair, 2*pair+1) starting at absolute index a0,
 // when they lie contiguously in one buffer: kind 1 = float32 frames with the two channels side by side (one 8-byte
 // word per sample), kind 2 = the two planar fp64 rings, kind 0 = not contiguous (use fifo_get / fifo_put).
@@ -95,8 +119,9 @@ struct PairSpan {
   }
 };
 
-__device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len)
+__device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len, int ca = -1)
 {
+  if (ca < 0) ca = 2 * pair; // (pair_channels: differs only with an odd channel count per stream, where float frames are never contiguous pairs)
   PairSpan r;
   r.kind = 0;
   r.p2 = nullptr;
@@ -119,7 +144,7 @@ __device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool h
     }
   } else if ((a0 & v.d.mask) + len <= v.d.mask + 1) {
     r.kind = 2;
-    r.pa = v.d.ring + (long long)(2 * pair) * v.d.chan_stride + (a0 & v.d.mask);
+    r.pa = v.d.ring + (long long)ca * v.d.chan_stride + (a0 & v.d.mask);
     r.pb = hasb ? r.pa + v.d.chan_stride : r.pa;
   }
   return r;

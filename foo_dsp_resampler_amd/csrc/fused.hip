@@ -79,7 +79,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   const int tid = threadIdx.x;
-  const int npairs = (a.d.C + 1) >> 1;
+  const int npairs = pair_count(a.d.C, a.d.nchs);
   const int V = a.d.V;
   const bool fwd_active = tid < TF;
   const double2 *__restrict__ Gp = a.d.G;
@@ -114,8 +114,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
     int bl, pair;
     if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
     const long long B = a.d.B0 + bl;
-    const int ca = 2 * pair, cb = ca + 1;
-    const bool hasb = cb < a.d.C;
+    const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs);
+    const int ca = pc.ca, cb = pc.cb;
+    const bool hasb = pc.hasb;
 
     // ---------------------------------------------------------------- load the block (fp32 -> fp64)
     // L = 2 in the matrix-pipe variant: the forward transform has half the points of the inverse one and runs
@@ -166,7 +167,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
             v[s] = {(double)f.x, (double)f.y};
           }
         } else {
-          const PairSpan sp = in.is_f32 ? PairSpan{0, nullptr, 1, nullptr, nullptr, hasb} : pair_span(in, pair, hasb, e0, P);
+          const PairSpan sp = in.is_f32 ? PairSpan{0, nullptr, 1, nullptr, nullptr, hasb} : pair_span(in, pair, hasb, e0, P, ca);
           if (sp.kind) { // planar fp64 rings (the producer is another stage), block contiguous in both
 #pragma unroll
             for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
@@ -668,7 +669,7 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
   }
   FusedArgs b = a;
   b.d.hp = frame_pairs(in, out, a.d.C);
-  dim3 grid(item_grid(a.d.nblocks, (a.d.C + 1) / 2, b.d.hp)), block(N / 16);
+  dim3 grid(item_grid(a.d.nblocks, pair_count(a.d.C, a.d.nchs), b.d.hp)), block(N / 16);
   hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), grid, block, lds_bytes, st, in, out, b);
   return hipGetLastError();
 }

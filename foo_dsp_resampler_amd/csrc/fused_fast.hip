@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         // one unconditional buffer store per tile: outputs in front of the block (ib < 0 wraps to a huge offset) and behind
         // the round's last one fail the descriptor's range check and are dropped by the hardware; only the residue test of
         // the last (partial) group needs a select
-        const unsigned off = (16 * g + rloc < pl) ? (unsigned)(ib * frame_bytes) : 0xffffffffu;
+        const unsigned off = (16 * g + rloc < pl) ? (unsigned)__mul24(ib, frame_bytes) : 0xffffffffu; // |ib| < 2^23: full-rate multiply
         const rsmp_v2u d = {__float_as_uint((float)accA), __float_as_uint((float)accB)};
         __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (int)off, 0, 0);
       }

@@ -57,10 +57,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
 
   const int tid = threadIdx.x;
   int bl, pair;
-  if (!item_map(blockIdx.x, a.nblocks, (a.C + 1) >> 1, a.hp, bl, pair)) return; // uniform
+  if (!item_map(blockIdx.x, a.nblocks, pair_count(a.C, a.nchs), a.hp, bl, pair)) return; // uniform
   const long long B = a.B0 + bl;
-  const int ca = 2 * pair, cb = ca + 1;
-  const bool hasb = cb < a.C;
+  const PairCh pc = pair_channels(pair, a.C, a.nchs);
+  const int ca = pc.ca, cb = pc.cb;
+  const bool hasb = pc.hasb;
   const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
 
   c64 v[16];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   if constexpr (F8) {
     if (tid < T8) {
       const long long base = B * a.q;
-      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
       if (sp.kind) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) sp.get(tid + s * T8, u8[s].x, u8[s].y);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   if (fwd_active) {
     if (LOG2P < LOG2N || a.L == 1) {
       const long long base = B * a.q;
-      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+      const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
       if (sp.kind) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
       fft8_regs<LOG2ND, +1>(d8, tid, a.tw_inv8, lds);
       const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
       const long long o0 = B * a.Vout;
-      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout)
+      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout, ca)
                                                                        : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
     if (a.M == 1) {
       const long long o0 = B * a.Vout;
-      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout)
+      const PairSpan so = (o0 >= a.clip_lo && o0 + a.Vout <= a.clip_hi) ? pair_span(out, pair, hasb, a.out_offset + o0, a.Vout, ca)
                                                                        : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -554,7 +555,7 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
   }
   DftArgs b = a;
   b.hp = frame_pairs(in, out, a.C);
-  dim3 grid(item_grid(a.nblocks, (a.C + 1) / 2, b.hp)), block(N / 16);
+  dim3 grid(item_grid(a.nblocks, pair_count(a.C, a.nchs), b.hp)), block(N / 16);
   hipLaunchKernelGGL((dft_kernel<LOG2N, LOG2P, LOG2ND>), grid, block, lds_bytes, st, in, out, b);
   return hipGetLastError();
 }

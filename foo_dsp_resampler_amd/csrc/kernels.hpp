@@ -48,10 +48,14 @@ struct DftArgs {
   int Vout;              // outputs kept per block when M == 1 (V, or the frequency-domain decimated count)
   int q;                 // inputs consumed per block (frequency-domain paths)
   int M;                 // time-domain decimation step (1 = none)
+  int nchs;              // > 0: channels per stream of a batch handle whose pairs must not straddle streams (pair_channels); else 0
   int hp;                // channel pairs per interleaved float frame whose workgroups are co-located (item_map); 0/1 = none
   long long in_limit;    // input items at absolute index >= in_limit read as zero (unused by the engine: always +inf)
   long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored (always everything)
 };
+
+// number of channel pairs (= workgroups per block) of a launch, see pair_channels (fifo_device.hpp)
+__host__ __device__ inline int pair_count(int C, int nchs) { return nchs > 0 ? (C / nchs) * ((nchs + 1) >> 1) : (C + 1) >> 1; }
 
 // Long blocks (N = 32768 ... 131072): N = 16 x M four-step transform in three launches through a workspace (dftbig.hip)
 struct BigDftArgs {
@@ -220,6 +224,7 @@ struct PolyMfArgs {
   long long out_offset;  // preload of the destination fifo
   long long in_limit;    // stage-input samples at absolute index >= in_limit are not written yet: read as zero
   int nblocks, C, Vt, n, polyL, step, NGRP;
+  int nchs;              // as DftArgs::nchs
 };
 bool polymf_supported(int ksteps);
 hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,

@@ -20,11 +20,12 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double2 *smp = reinterpret_cast<double2 *>(lds) + kPmPad; // smp[n] = sample b0 + n of (channel A, channel B)
   const int tid = threadIdx.x;
-  const int npairs = (a.C + 1) >> 1;
+  const int npairs = pair_count(a.C, a.nchs);
   const int w = blockIdx.x;
   const int bl = w / npairs, pair = w - bl * npairs;
-  const int ca = 2 * pair, cb = ca + 1;
-  const bool hasb = cb < a.C;
+  const PairCh pc = pair_channels(pair, a.C, a.nchs);
+  const int ca = pc.ca, cb = pc.cb;
+  const bool hasb = pc.hasb;
   const FusedBlock fb = a.blk[bl];
   if (fb.cnt <= 0) return; // uniform
   const long long b0 = (a.B0 + bl) * (long long)a.Vt;
@@ -32,7 +33,7 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   const int W = a.Vt + a.n + 4; // samples any stored output of this tile can touch
 
   { // stage the window; positions the producer has not written yet read as zero (only unstored outputs see them)
-    const PairSpan sp = b0 + W <= a.in_limit ? pair_span(in, pair, hasb, b0, W) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+    const PairSpan sp = b0 + W <= a.in_limit ? pair_span(in, pair, hasb, b0, W, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
     if (sp.kind) {
       for (int i = tid; i < W; i += 256) {
         double x, y;
@@ -173,7 +174,7 @@ hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &
   if (kname) *kname = ksteps == 7 ? "rsmp::polymf_kernel<7>" : ksteps == 8 ? "rsmp::polymf_kernel<8>" : "rsmp::polymf_kernel<9>";
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const size_t lds_bytes = size_t(kPmPad + a.Vt + a.n + 4 + kPmPad) * 16;
-  dim3 grid(a.nblocks * ((a.C + 1) / 2)), block(256);
+  dim3 grid(a.nblocks * pair_count(a.C, a.nchs)), block(256);
   if (ksteps == 7) hipLaunchKernelGGL(polymf_kernel<7>, grid, block, lds_bytes, st, in, out, a);
   else if (ksteps == 8) hipLaunchKernelGGL(polymf_kernel<8>, grid, block, lds_bytes, st, in, out, a);
   else if (ksteps == 9) hipLaunchKernelGGL(polymf_kernel<9>, grid, block, lds_bytes, st, in, out, a);

@@ -201,3 +201,28 @@ def test_interpolated_polyphase_rows_shared_across_channel_groups(fi, fo, kw):
         ref = Oracle(fi, fo, nch, **kw).process(xs[s], chunk=6500)
         assert got[s].shape == ref.shape
         assert_parity(got[s], ref)
+
+
+@pytest.mark.parametrize("fi,fo,kw", [
+    (44100, 48000, {}),                       # dft x2 -> vpoly0, fused
+    (96000, 44100, {}),                       # dft -> vpoly0 147/320, fused (vector variant)
+    (48000, 192000, {}),                      # dft x4 as four component transforms (dftx_kernel)
+    (44100, 192000, {"bandwidth": 99.0}),     # 16384-point stage -> polymf_kernel -> dftx_kernel
+    (48000, 192000, {"bandwidth": 99.0}),     # 32768-point blocks (four-step transform)
+    (44100, 48001, {}),                       # vpoly3 (shared interpolated rows)
+    (192000, 44100, {}),                      # half-band -> dft -> vpoly0
+])
+def test_odd_channel_batch_gives_every_stream_its_own_bits(fi, fo, kw):
+    """with an odd channel count the channel pairs of a batch handle used to straddle streams, so a
+    stream's bits depended on its neighbours (within 1 ulp).  Pairs now stay inside a stream (pair_channels), and every
+    stream of the batch must equal -- bit for bit -- what a one-stream handle gives for the same samples."""
+    S, nch, n = 3, 3, 30000
+    xs = np.stack([lcg_noise(n, nch, 4321 + s) for s in range(S)])
+    got = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw).process(xs, chunk=7000)
+    for s in range(S):
+        ref = F.Resampler(fi, fo, nch=nch, **kw).process(xs[s], chunk=7000)
+        assert got[s].shape == ref.shape, (s, got[s].shape, ref.shape)
+        assert np.array_equal(got[s].view(np.uint32), ref.view(np.uint32)), (fi, fo, kw, s)
+    ora = Oracle(fi, fo, nch, **kw).process(xs[1], chunk=7000)
+    assert got[1].shape == ora.shape
+    assert_parity(got[1], ora)

@@ -2,10 +2,8 @@
 """Seeded random sweep of the device-pointer / batch API: S lock-stepped streams pushed and pulled through
 RRX_flow_device / RRX_push_device / RRX_pull_device with random chunking and random output capacities (so that
 outputs land partly in the caller's buffer, partly in the ring) must give, per stream, exactly the bits the
-single-stream host API gives for that stream's samples -- when nch is even.  With an odd channel count the batch
-pairs the last channel of one stream with the first of the next in one complex transform, so a stream's output
-depends on its neighbour at the level of fp64 rounding (seen: one float32 sample in 300 000, 1e-13 absolute);
-those cases are held to the normal parity bar instead."""
+single-stream host API gives for that stream's samples -- odd channel counts included: channel pairs never straddle
+two streams (pair_channels in csrc/fifo_device.hpp)."""
 import os
 import sys
 
@@ -16,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import foo_dsp_resampler_amd as F  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from parity import compare_f32  # noqa: E402
 
 RATES = [8000, 11025, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
 
@@ -26,7 +23,7 @@ def main(n_cases, seed):
     bad = 0
     for k in range(n_cases):
         fi, fo = [int(v) for v in rng.choice(RATES, 2, replace=False)]
-        nch = int(rng.choice([1, 2, 2, 4, 6]))
+        nch = int(rng.choice([1, 2, 2, 3, 4, 5, 6]))
         S = int(rng.choice([1, 2, 3, 8]))
         kw = {}
         if rng.rand() < 0.3:
@@ -66,9 +63,6 @@ def main(n_cases, seed):
         for s in range(S):
             ref = F.Resampler(fi, fo, nch=nch, **kw).process(x[s].cpu().numpy())
             same = got[s].shape == ref.shape and np.array_equal(got[s].view(np.uint32), ref.view(np.uint32))
-            if not same and got[s].shape == ref.shape and (nch & 1) and S > 1:
-                rep = compare_f32(got[s], ref)
-                same = rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7
             if not same:
                 bad += 1
                 print("MISMATCH case", k, fi, fo, nch, S, kw, frames, "stream", s, got[s].shape, ref.shape)
