@@ -1163,8 +1163,8 @@ int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, flo
     if (rc) return rc;
     done += n;
   }
-  { int rcj = join_side(); if (rcj) return rcj; }
-  // carry the part of this push that no stage has consumed yet into ring 0
+  // carry the part of this push that no stage has consumed yet into ring 0 (while the seam kernels, which only write
+  // stage outputs, still run on the side stream)
   const long long a0 = std::max(book_.rd[0], ein.begin), a1 = book_.wr[0];
   if (a1 > a0) {
     int rc = ensure_ring(0, book_.wr[0] - book_.rd[0]);
@@ -1173,6 +1173,7 @@ int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, flo
     F64View nod = {};
     HIP_TRY(launch_copy(true, src, nod, dst, nod, a0, a1, C_, stream_));
   }
+  { int rcj = join_side(); if (rcj) return rcj; }
   if (eout.ptr) {
     const long long produced = book_.wr.back() - wr_out0;
     const long long direct = std::min<long long>(produced, (long long)out_cap);

@@ -600,34 +600,46 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
 {
   __shared__ double win[kSeamC][kSeamWin];
   __shared__ double cfs[kSeamOut][32];
+  __shared__ int qs[kSeamOut];
   const int bl = blockIdx.x, c0 = blockIdx.y * kSeamC, tid = threadIdx.x;
   const long long B = a.d.B0 + bl;
   const int nm1 = a.n - 1, pl = a.polyL, step = a.step, n = a.n;
   const int nc = min(kSeamC, a.d.C - c0);
   const FusedBlock fb = a.blk[bl];
   const int cnt = min((int)(fb.i_lo - fb.seam_i0), kSeamOut); // at most ~(n - 1) * L / step + 1 outputs per boundary (host-checked <= 64)
-  for (int idx = tid; idx < nc * 2 * nm1; idx += 256) {
-    const int cl = idx / (2 * nm1), k = idx - cl * (2 * nm1), c = c0 + cl;
-    const double *tail = a.seam + ((long long)((int)((B - 1) & a.seam_mask) * (a.d.C + 1) + c) * 2 + 1) * 32;
-    const double *head = a.seam + ((long long)((int)(B & a.seam_mask) * (a.d.C + 1) + c) * 2) * 32;
-    win[cl][k] = k < nm1 ? (B == 0 ? 0.0 : tail[k]) : head[k - nm1];
+  // (no divisions by run-time values in the loops: thread = (row, column) of every tile it touches)
+  { // windows [tail of B-1 | head of B]: lane k of a 64-lane row, 4 channels per pass
+    const int k = tid & 63;
+    const double *const tails = a.seam + ((long long)((int)((B - 1) & a.seam_mask) * (a.d.C + 1) + c0) * 2 + 1) * 32;
+    const double *const heads = a.seam + ((long long)((int)(B & a.seam_mask) * (a.d.C + 1) + c0) * 2) * 32;
+    if (k < 2 * nm1) {
+      for (int cl = tid >> 6; cl < nc; cl += 4)
+        win[cl][k] = k < nm1 ? (B == 0 ? 0.0 : tails[cl * 64 + k]) : heads[cl * 64 + k - nm1];
+    }
   }
-  for (int idx = tid; idx < cnt * n; idx += 256) {
-    const int u = idx / n, j = idx - u * n;
-    const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
-    const unsigned ph = t % (unsigned)pl;
-    cfs[u][j] = a.tab[(long long)ph * n + j];
+  { // coefficient rows of the boundary's outputs: lane j of a 32-lane row, 8 outputs per pass
+    const int j = tid & 31;
+    for (int u = tid >> 5; u < cnt; u += 8) {
+      const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
+      const unsigned q = t / (unsigned)pl, ph = t - q * (unsigned)pl;
+      if (j < n) cfs[u][j] = a.tab[(long long)ph * n + j];
+      if (j == 0) qs[u] = fb.seam_q0 + (int)q; // window start inside [tail | head], 0 <= . < n-1
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < cnt * nc; idx += 256) {
-    const int u = idx / nc, cl = idx - u * nc; // neighbouring lanes: neighbouring channels of one output
-    const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step;
-    const double *x = win[cl] + fb.seam_q0 + (int)(t / (unsigned)pl); // window start inside [tail | head], 0 <= . < n-1
-    const double *cf = cfs[u];
-    double sum = 0.0;
+  { // neighbouring lanes: neighbouring channels of one output; 4 outputs per pass
+    const int cl = tid & 63;
+    if (cl < nc) {
+      const ChanRef oc = chan_ref(out, c0 + cl);
+      for (int u = tid >> 6; u < cnt; u += 4) {
+        const double *x = win[cl] + qs[u];
+        const double *cf = cfs[u];
+        double sum = 0.0;
 #pragma unroll 8
-    for (int j = 0; j < n; ++j) sum = fma(cf[j], x[j], sum); // the reference's tap order
-    fifo_put(chan_ref(out, c0 + cl), a.out_offset2 + fb.seam_i0 + u, sum);
+        for (int j = 0; j < n; ++j) sum = fma(cf[j], x[j], sum); // the reference's tap order
+        fifo_put(oc, a.out_offset2 + fb.seam_i0 + u, sum);
+      }
+    }
   }
 }
 
