@@ -38,10 +38,10 @@ __global__ __launch_bounds__(256) void big_cols_fwd_kernel(AnyView in, BigDftArg
   const int item = blockIdx.y; // within this launch
   const int Mp = 1 << a.log2mp;
   if (n2 >= Mp) return;
-  const int git = a.item0 + item, npairs = pair_count(a.d.C, a.d.nchs);
+  const int git = a.item0 + item, npairs = a.d.npairs;
   const int bl = git / npairs, pair = git - bl * npairs;
   const long long B = a.d.B0 + bl;
-  const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs);
+  const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs, a.d.pps_magic);
   const int ca = pc.ca, cb = pc.cb;
   const bool hasb = pc.hasb;
   const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(256) void big_cols_inv_kernel(AnyView out, BigDftAr
   const int item = blockIdx.y;
   const int Md = 1 << a.log2md;
   if (m2 >= Md) return;
-  const int git = a.item0 + item, npairs = pair_count(a.d.C, a.d.nchs);
+  const int git = a.item0 + item, npairs = a.d.npairs;
   const int bl = git / npairs, pair = git - bl * npairs;
   const long long B = a.d.B0 + bl;
-  const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs);
+  const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs, a.d.pps_magic);
   const int ca = pc.ca, cb = pc.cb;
   const bool hasb = pc.hasb;
   const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
@@ -246,7 +246,9 @@ hipError_t launch_dft_big(bool src_f32, bool dst_f32, const F32View &sf, const F
                           BigDftArgs a, int ws_items, hipStream_t st)
 {
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
-  const int npairs = pair_count(a.d.C, a.d.nchs);
+  a.d.npairs = pair_count(a.d.C, a.d.nchs);
+  a.d.pps_magic = pair_magic(a.d.C, a.d.nchs);
+  const int npairs = a.d.npairs;
   const long long total = (long long)a.d.nblocks * npairs;
   const int Mp = 1 << a.log2mp, Md = 1 << a.log2md;
   for (long long i0 = 0; i0 < total; i0 += ws_items) {

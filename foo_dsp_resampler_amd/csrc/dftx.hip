@@ -118,9 +118,9 @@ template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kern
 
   const int tid = threadIdx.x;
   int bl, pair;
-  if (!item_map(blockIdx.x, a.nblocks, pair_count(a.C, a.nchs), a.hp, bl, pair)) return; // uniform
+  if (!item_map(blockIdx.x, a.nblocks, a.npairs, a.hp, bl, pair)) return; // uniform
   const long long B = a.B0 + bl;
-  const PairCh pc = pair_channels(pair, a.C, a.nchs);
+  const PairCh pc = pair_channels(pair, a.C, a.nchs, a.pps_magic);
   const int ca = pc.ca, cb = pc.cb;
   const bool hasb = pc.hasb;
 
@@ -270,7 +270,7 @@ template <int LL, int OKIND> static hipError_t launch_dftx_run(const AnyView &in
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
   }
-  dim3 grid(item_grid(a.nblocks, pair_count(a.C, a.nchs), a.hp)), block(256);
+  dim3 grid(item_grid(a.nblocks, a.npairs, a.hp)), block(256);
   hipLaunchKernelGGL((dftx_kernel<LL, OKIND>), grid, block, kXLdsBytes, st, in, out, a);
   return hipGetLastError();
 }
@@ -281,6 +281,8 @@ template <int LL> static hipError_t launch_dftx_t(const AnyView &in, const AnyVi
 {
   DftArgs b = a;
   b.hp = frame_pairs(in, out, a.C);
+  b.npairs = pair_count(a.C, a.nchs);
+  b.pps_magic = pair_magic(a.C, a.nchs);
   const bool clip_all = a.clip_lo <= a.B0 * (long long)a.Vout && (a.B0 + a.nblocks) * (long long)a.Vout <= a.clip_hi;
   auto fast = [&](int k) {
     const long long B = a.B0 + k;

@@ -73,19 +73,16 @@ struct PairCh {
   int ca, cb;
   bool hasb;
 };
-__device__ __forceinline__ PairCh pair_channels(int pair, int C, int nchs)
+__device__ __forceinline__ PairCh pair_channels(int pair, int C, int nchs, unsigned pps_magic)
 {
+  // One branch-free, division-free, wave-uniform form for both cases: with nchs = 0 the whole handle counts as one
+  // "stream" of C channels.  pps_magic = ceil(2^32 / pairs per stream) (pair_magic; 0 = one pair per stream), exact for pair < 2^32 / pps.
+  const int ncs = nchs > 0 ? nchs : C, pps = (ncs + 1) >> 1;
+  const int strm = pps_magic ? (int)__umulhi((unsigned)pair, pps_magic) : pair /* one pair per stream */, pin = pair - strm * pps;
   PairCh r;
-  if (nchs <= 0) {
-    r.ca = 2 * pair;
-    r.cb = r.ca + 1;
-    r.hasb = r.cb < C;
-  } else {
-    const int pps = (nchs + 1) >> 1, strm = pair / pps, pin = pair - strm * pps;
-    r.ca = strm * nchs + 2 * pin;
-    r.cb = r.ca + 1;
-    r.hasb = 2 * pin + 1 < nchs;
-  }
+  r.ca = __builtin_amdgcn_readfirstlane(strm * ncs + 2 * pin);
+  r.cb = r.ca + 1;
+  r.hasb = __builtin_amdgcn_readfirstlane(2 * pin + 1 < ncs) != 0;
   return r;
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   const int tid = threadIdx.x;
-  const int npairs = pair_count(a.d.C, a.d.nchs);
+  const int npairs = a.d.npairs;
   const int V = a.d.V;
   const bool fwd_active = tid < TF;
   const double2 *__restrict__ Gp = a.d.G;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
     int bl, pair;
     if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
     const long long B = a.d.B0 + bl;
-    const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs);
+    const PairCh pc = pair_channels(pair, a.d.C, a.d.nchs, a.d.pps_magic);
     const int ca = pc.ca, cb = pc.cb;
     const bool hasb = pc.hasb;
 
@@ -681,7 +681,9 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
   }
   FusedArgs b = a;
   b.d.hp = frame_pairs(in, out, a.d.C);
-  dim3 grid(item_grid(a.d.nblocks, pair_count(a.d.C, a.d.nchs), b.d.hp)), block(N / 16);
+  b.d.npairs = pair_count(a.d.C, a.d.nchs);
+  b.d.pps_magic = pair_magic(a.d.C, a.d.nchs);
+  dim3 grid(item_grid(a.d.nblocks, b.d.npairs, b.d.hp)), block(N / 16);
   hipLaunchKernelGGL((fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), grid, block, lds_bytes, st, in, out, b);
   return hipGetLastError();
 }

@@ -39,7 +39,10 @@ template <bool SPLIT> struct LdsCx {
   }
 };
 
-template <int LOG2N, int LOG2P, int LOG2ND>
+// SP ("stream pairs"): the channel pairs of a batch handle with an odd channel count per stream, which must not straddle
+// streams (pair_channels).  Its own instance because the general pair -> channel map costs the 128-VGPR instances a few
+// registers they do not have (dft_kernel<14, 13, 14>: 10 -> 14 spilled VGPRs, +4 % time); every other handle runs SP = false.
+template <int LOG2N, int LOG2P, int LOG2ND, bool SP>
 __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 4 : (LOG2N == 12 && LOG2ND >= 11) ? 3 : 1) void dft_kernel(AnyView in, AnyView out, DftArgs a)
 {
   constexpr int N = 1 << LOG2N, P = 1 << LOG2P, ND = 1 << LOG2ND;
@@ -57,11 +60,16 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
 
   const int tid = threadIdx.x;
   int bl, pair;
-  if (!item_map(blockIdx.x, a.nblocks, pair_count(a.C, a.nchs), a.hp, bl, pair)) return; // uniform
+  if (!item_map(blockIdx.x, a.nblocks, a.npairs, a.hp, bl, pair)) return; // uniform
   const long long B = a.B0 + bl;
-  const PairCh pc = pair_channels(pair, a.C, a.nchs);
-  const int ca = pc.ca, cb = pc.cb;
-  const bool hasb = pc.hasb;
+  int ca = 2 * pair, cb = ca + 1;
+  bool hasb = cb < a.C;
+  if constexpr (SP) {
+    const PairCh pc = pair_channels(pair, a.C, a.nchs, a.pps_magic);
+    ca = pc.ca;
+    cb = pc.cb;
+    hasb = pc.hasb;
+  }
   const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
 
   c64 v[16];
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(256) void copy_kernel(AnyView in, AnyView out, long
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int LOG2N, int LOG2P, int LOG2ND>
+template <int LOG2N, int LOG2P, int LOG2ND, bool SP>
 static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
@@ -548,22 +556,24 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
                                    : 8 * size_t(fft_lds_doubles(LOG2N)));
   static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
   if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND, SP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
   }
   DftArgs b = a;
   b.hp = frame_pairs(in, out, a.C);
-  dim3 grid(item_grid(a.nblocks, pair_count(a.C, a.nchs), b.hp)), block(N / 16);
-  hipLaunchKernelGGL((dft_kernel<LOG2N, LOG2P, LOG2ND>), grid, block, lds_bytes, st, in, out, b);
+  b.npairs = pair_count(a.C, a.nchs);
+  b.pps_magic = pair_magic(a.C, a.nchs);
+  dim3 grid(item_grid(a.nblocks, b.npairs, b.hp)), block(N / 16);
+  hipLaunchKernelGGL((dft_kernel<LOG2N, LOG2P, LOG2ND, SP>), grid, block, lds_bytes, st, in, out, b);
   return hipGetLastError();
 }
 
 #define RSMP_DFT_CASE(n, p, d)                                         \
   if (log2n == n && log2p == p && log2nd == d) {                       \
-    if (kname) *kname = "rsmp::dft_kernel<" #n ", " #p ", " #d ">";    \
-    return launch_dft_t<n, p, d>(in, out, a, st);                      \
+    if (kname) *kname = a.nchs > 0 ? "rsmp::dft_kernel<" #n ", " #p ", " #d ", true>" : "rsmp::dft_kernel<" #n ", " #p ", " #d ", false>"; \
+    return a.nchs > 0 ? launch_dft_t<n, p, d, true>(in, out, a, st) : launch_dft_t<n, p, d, false>(in, out, a, st); \
   }
 #define RSMP_DFT_SIZE(n, n1, n2) \
   RSMP_DFT_CASE(n, n, n)          \

@@ -49,6 +49,8 @@ struct DftArgs {
   int q;                 // inputs consumed per block (frequency-domain paths)
   int M;                 // time-domain decimation step (1 = none)
   int nchs;              // > 0: channels per stream of a batch handle whose pairs must not straddle streams (pair_channels); else 0
+  int npairs;            // pair_count(C, nchs), filled in by the launchers
+  unsigned pps_magic;    // ceil(2^32 / pairs per stream) when nchs > 0 (pair_magic), filled in by the launchers
   int hp;                // channel pairs per interleaved float frame whose workgroups are co-located (item_map); 0/1 = none
   long long in_limit;    // input items at absolute index >= in_limit read as zero (unused by the engine: always +inf)
   long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored (always everything)
@@ -56,6 +58,12 @@ struct DftArgs {
 
 // number of channel pairs (= workgroups per block) of a launch, see pair_channels (fifo_device.hpp)
 __host__ __device__ inline int pair_count(int C, int nchs) { return nchs > 0 ? (C / nchs) * ((nchs + 1) >> 1) : (C + 1) >> 1; }
+
+__host__ __device__ inline unsigned pair_magic(int C, int nchs)
+{
+  const unsigned long long pps = (unsigned long long)(((nchs > 0 ? nchs : C) + 1) >> 1);
+  return pps <= 1 ? 0u : (unsigned)(((1ull << 32) + pps - 1) / pps); // 0: one pair per stream, no division
+}
 
 // Long blocks (N = 32768 ... 131072): N = 16 x M four-step transform in three launches through a workspace (dftbig.hip)
 struct BigDftArgs {
@@ -224,7 +232,8 @@ struct PolyMfArgs {
   long long out_offset;  // preload of the destination fifo
   long long in_limit;    // stage-input samples at absolute index >= in_limit are not written yet: read as zero
   int nblocks, C, Vt, n, polyL, step, NGRP;
-  int nchs;              // as DftArgs::nchs
+  int nchs, npairs;      // as DftArgs::nchs / npairs
+  unsigned pps_magic;    // as DftArgs::pps_magic
 };
 bool polymf_supported(int ksteps);
 hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,

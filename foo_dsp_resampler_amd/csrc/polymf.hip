@@ -20,10 +20,10 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double2 *smp = reinterpret_cast<double2 *>(lds) + kPmPad; // smp[n] = sample b0 + n of (channel A, channel B)
   const int tid = threadIdx.x;
-  const int npairs = pair_count(a.C, a.nchs);
+  const int npairs = a.npairs;
   const int w = blockIdx.x;
   const int bl = w / npairs, pair = w - bl * npairs;
-  const PairCh pc = pair_channels(pair, a.C, a.nchs);
+  const PairCh pc = pair_channels(pair, a.C, a.nchs, a.pps_magic);
   const int ca = pc.ca, cb = pc.cb;
   const bool hasb = pc.hasb;
   const FusedBlock fb = a.blk[bl];
@@ -174,10 +174,13 @@ hipError_t launch_polymf(int ksteps, bool src_f32, bool dst_f32, const F32View &
   if (kname) *kname = ksteps == 7 ? "rsmp::polymf_kernel<7>" : ksteps == 8 ? "rsmp::polymf_kernel<8>" : "rsmp::polymf_kernel<9>";
   const AnyView in = make_view(src_f32, sf, sd), out = make_view(dst_f32, df, dd);
   const size_t lds_bytes = size_t(kPmPad + a.Vt + a.n + 4 + kPmPad) * 16;
-  dim3 grid(a.nblocks * pair_count(a.C, a.nchs)), block(256);
-  if (ksteps == 7) hipLaunchKernelGGL(polymf_kernel<7>, grid, block, lds_bytes, st, in, out, a);
-  else if (ksteps == 8) hipLaunchKernelGGL(polymf_kernel<8>, grid, block, lds_bytes, st, in, out, a);
-  else if (ksteps == 9) hipLaunchKernelGGL(polymf_kernel<9>, grid, block, lds_bytes, st, in, out, a);
+  PolyMfArgs b = a;
+  b.npairs = pair_count(a.C, a.nchs);
+  b.pps_magic = pair_magic(a.C, a.nchs);
+  dim3 grid(a.nblocks * b.npairs), block(256);
+  if (ksteps == 7) hipLaunchKernelGGL(polymf_kernel<7>, grid, block, lds_bytes, st, in, out, b);
+  else if (ksteps == 8) hipLaunchKernelGGL(polymf_kernel<8>, grid, block, lds_bytes, st, in, out, b);
+  else if (ksteps == 9) hipLaunchKernelGGL(polymf_kernel<9>, grid, block, lds_bytes, st, in, out, b);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
