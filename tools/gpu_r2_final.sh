@@ -21,6 +21,8 @@ for k in 1 2; do
 done
 timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $O/pmc_cfg1_sq1 -o run -- python3 bench.py --config 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_cfg1_sq1.log 2>&1
 timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_cfg1_sq2 -o run -- python3 bench.py --config 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_cfg1_sq2.log 2>&1
+# the vector L1 (TCP) of the headline kernel: misses (128-byte lines, all L2 hits but the input) and cycles stalled on pending misses
+timeout -k 10 120 rocprofv3 --kernel-trace --pmc TCP_PENDING_STALL_CYCLES TCP_CACHE_MISS TCP_PERF_SEL_TOTAL_READ TCP_PERF_SEL_TOTAL_NONREAD GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_cfg1_tcp -o run -- python3 bench.py --config 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_cfg1_tcp.log 2>&1
 python3 - <<PY
 import csv, collections, glob
 for d in sorted(glob.glob("$O/stats_cfg*")):
