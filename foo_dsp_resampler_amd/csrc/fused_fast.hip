@@ -39,6 +39,11 @@
 #ifndef RSMP_BUFSTORE
 #define RSMP_BUFSTORE 1
 #endif
+// timing experiments only (WRONG results): bit 0 = every coefficient tile is group 0's, bit 1 = every G value is slot 0's
+// (the loads stay, their L1 misses go: upper bounds of what smaller / shared tables could buy)
+#ifndef RSMP_EXP_TAB
+#define RSMP_EXP_TAB 0
+#endif
 #ifndef RSMP_EXP_LINEAR
 #define RSMP_EXP_LINEAR 0
 #endif
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   if constexpr (FWD8) {
     double2 g[16]; // in flight during the whole forward transform
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + s * T);
+    for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + (RSMP_EXP_TAB & 2 ? 0 : s * T));
     fft8_regs<LOG2P, -1, RSMP_TWGEN != 0>(u8, tid, a.d.tw_fwd8, lds);
     RSMP_STAMP(1)
 #pragma unroll
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     int qc, qn = 0;
     auto load_tile = [&](int gg, double (&c_)[KS], int &q_) {
       constexpr int KSP = (KS + 1) / 2;
-      const double2 *cp = cfm_lane + gg * (KSP * 64); // uniform offset; two k-steps per 16-byte load
+      const double2 *cp = cfm_lane + (RSMP_EXP_TAB & 1 ? 0 : gg) * (KSP * 64); // uniform offset; two k-steps per 16-byte load
 #pragma unroll
       for (int s2 = 0; s2 < KSP; ++s2) {
         const double2 d = cp[s2 * 64];
