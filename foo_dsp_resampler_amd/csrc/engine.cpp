@@ -315,13 +315,15 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       int qb_min = at0 / p.L, qb_max = qb_min;
       for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
       // ... and at most 32 periods per block (4 column steps per item), enough phases to fill 16-row tiles
-      // ... and the four periods of a tile (lanes j = 0..3 of a B read, `step` samples apart) must not fall on the same LDS
-      // banks: 16-byte samples, 16 of them per bank row, so j*step mod 16 has to take four values.  96k->44.1k (step 320)
-      // fails that -- every ds_read_b128 a 4-way conflict, measured 3.90 ms against 3.74 ms for the vector variant.
+      // (The four periods of a tile -- lanes j = 0..3 of a B read, `step` samples apart -- fall on the same LDS banks when
+      // step is a multiple of 8 samples: 96k->44.1k (step 320), 48k->44.1k (160).  Such chains used to be kept on the vector
+      // variant (3.90 against 3.74 ms at the time); with the lean kernel's later gains the matrix-pipe variant wins despite
+      // its 4-way conflicts: 96k->44.1k 3.26 against 3.74 ms, 48k->44.1k +25 %.  RSMP_SPREAD_VECTOR=1 restores the old choice.)
       bool lanes_spread = true;
-      for (int j1 = 0; j1 < 4; ++j1)
-        for (int j2 = j1 + 1; j2 < 4; ++j2)
-          if (((j2 - j1) * pstep) % 16 == 0) lanes_spread = false;
+      if (getenv("RSMP_SPREAD_VECTOR"))
+        for (int j1 = 0; j1 < 4; ++j1)
+          for (int j2 = j1 + 1; j2 < 4; ++j2)
+            if (((j2 - j1) * pstep) % 16 == 0) lanes_spread = false;
       const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && lanes_spread;
       if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
