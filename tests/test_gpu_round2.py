@@ -226,3 +226,35 @@ def test_odd_channel_batch_gives_every_stream_its_own_bits(fi, fo, kw):
     ora = Oracle(fi, fo, nch, **kw).process(xs[1], chunk=7000)
     assert got[1].shape == ora.shape
     assert_parity(got[1], ora)
+
+
+@pytest.mark.parametrize("fi,fo,nch,kw", [
+    (48000, 192000, 2, {}),                       # one x4 stage, float frames on both sides
+    (44100, 176400, 8, {}),                       # the same on 8-channel frames (four pair-workgroups share every frame)
+    (22050, 88200, 1, {}),                        # a single channel: the pair's second half is empty
+    (44100, 192000, 8, {"bandwidth": 99.0}),      # last stage of the 3-stage chain: fp64 ring in, float frames out
+])
+def test_x4_stage_as_component_transforms(fi, fo, nch, kw):
+    """dftx_kernel (csrc/dftx.hip): x4 upsampling on 8192-point blocks computed as the four 2048-point transforms of the
+    filter's polyphase components instead of the reference's one 8192-point inverse (dft_filter.h:86-104,118-156).  Same
+    parity bar against the oracle; bit-identical whatever the push sizes are (the lean instance takes the blocks with
+    contiguous spans, the generic one a block at a ring wrap or across two pushes -- same arithmetic)."""
+    n = 50000
+    x = lcg_noise(n, nch, 777)
+    ref = Oracle(fi, fo, nch, **kw).process(x)
+    one = F.Resampler(fi, fo, nch=nch, **kw).process(x)
+    assert one.shape == ref.shape
+    assert_parity(one, ref)
+    for chunk in (1777, 9000, 30011):
+        got = F.Resampler(fi, fo, nch=nch, **kw).process(x, chunk=chunk)
+        assert got.shape == one.shape and np.array_equal(got.view(np.uint32), one.view(np.uint32)), (fi, fo, nch, chunk)
+    torch = pytest.importorskip("torch")
+    r = F.Resampler(fi, fo, nch=nch, **kw)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    xd = torch.rand((1, 40000, nch), device="cuda") - 0.5
+    yd = torch.empty((1, int(40000 * fo / fi) + 4096, nch), device="cuda")
+    r.profile(True)
+    r.flow_device(xd, 40000, yd, yd.shape[1])
+    names = {k["kernel"] for k in r.profile_report()}
+    r.profile(False)
+    assert "rsmp::dftx_kernel<4>" in names, names
