@@ -247,7 +247,7 @@ def main():
         alg_bytes_step = units_per_step_rank * bytes_per_unit
         # roofline of the dominant kernel: in a fused chain it carries all of the step's algorithmic bytes; in a
         # modular chain the bytes belong to the whole sequence of stage kernels, so the chain time is the divisor
-        fused = dom["kernel"] is not None and "fused_kernel" in dom["kernel"]
+        fused = dom["kernel"] is not None and ("fused_kernel" in dom["kernel"] or "fused_fast_kernel" in dom["kernel"])
         div_ms = dom_ms_per_step if fused else chain_ms
         achieved_gbs = alg_bytes_step / (div_ms / 1e3) / 1e9 if div_ms else 0.0
         flops_unit = chain_flops_per_unit(plan, fi)
