@@ -440,41 +440,78 @@ template <int ORDER> __global__ __launch_bounds__(256) void polyi_kernel(AnyView
   const int wstride = a.win;          // doubles per channel window, odd (bank spread across channels)
   double *wrow = sh;                  // [kPolyiTile][n]
   double *win = sh + kPolyiTile * n;  // [kPolyiCh][wstride]
-  for (int idx = tid; idx < nc * wlen; idx += 256) {
-    const int cl = idx / wlen, k = idx - cl * wlen;
-    win[cl * wstride + k] = fifo_get(chan_ref(in, c0 + cl), a.rd + q0 + k);
-  }
-  for (int idx = tid; idx < cnt * n; idx += 256) {
-    const int u = idx / n, j = idx - u * n;
-    const long long A = a.at + (i0 + u) * a.step;
-    const unsigned frac = (unsigned)A;
-    const int ph = (int)(frac >> (32 - a.phase_bits));
-    const double t = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
-    const double *__restrict__ cf = a.tab + ((long long)ph * n + j) * (ORDER + 1);
-    double w;
-    if constexpr (ORDER == 3) {
-      const double2 c01 = *reinterpret_cast<const double2 *>(cf), c23 = *reinterpret_cast<const double2 *>(cf + 2);
-      w = fma(fma(fma(c01.x, t, c01.y), t, c23.x), t, c23.y);
-    } else if constexpr (ORDER == 1) {
-      const double2 c01 = *reinterpret_cast<const double2 *>(cf);
-      w = fma(c01.x, t, c01.y);
-    } else {
-      w = cf[0];
+  // (no loop divides by a run-time value: a thread is (row, column) of every tile it touches, and works out a channel's
+  // addressing once per channel, not once per element)
+  // (... and the loads of a phase are issued in batches before anything waits for them: one L2 round trip per batch, not
+  // per element -- the row phase used to be 16 dependent table reads per thread, half of the kernel's time)
+  { // channel windows: 64 lanes along a window, 4 channels per pass, up to 4 loads in flight per thread
+    const int k0 = tid & 63;
+    for (int cl = tid >> 6; cl < nc; cl += 4) {
+      const ChanRef src = chan_ref(in, c0 + cl);
+      for (int kb = k0; kb < wlen; kb += 256) {
+        double t[4];
 #pragma unroll
-      for (int o = 1; o <= ORDER; ++o) w = fma(w, t, cf[o]);
+        for (int i = 0; i < 4; ++i) t[i] = fifo_get(src, a.rd + q0 + min(kb + 64 * i, wlen - 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kb + 64 * i < wlen) win[cl * wstride + kb + 64 * i] = t[i];
+      }
     }
-    wrow[u * n + j] = w;
+  }
+  { // interpolated rows: 32 lanes along a row (n <= 32), 8 outputs per pass, 8 passes' table reads in flight
+    const int j = min(tid & 31, n - 1);
+    const bool jok = (tid & 31) < n;
+    constexpr int RB = 8;
+    for (int ub = tid >> 5; ub < cnt; ub += 8 * RB) {
+      double2 c01[RB], c23[RB];
+      double tt[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int u = min(ub + 8 * i, cnt - 1);
+        const long long A = a.at + (i0 + u) * a.step;
+        const unsigned frac = (unsigned)A;
+        const int ph = (int)(frac >> (32 - a.phase_bits));
+        tt[i] = (double)(unsigned)(frac << a.phase_bits) * (1.0 / 4294967296.0);
+        const double *__restrict__ cf = a.tab + ((long long)ph * n + j) * (ORDER + 1);
+        if constexpr (ORDER == 3) {
+          c01[i] = *reinterpret_cast<const double2 *>(cf);
+          c23[i] = *reinterpret_cast<const double2 *>(cf + 2);
+        } else if constexpr (ORDER == 1) {
+          c01[i] = *reinterpret_cast<const double2 *>(cf);
+          c23[i] = make_double2(0.0, 0.0);
+        } else { // ORDER == 2: c0, c1 | c2
+          c01[i] = make_double2(cf[0], cf[1]);
+          c23[i] = make_double2(cf[2], 0.0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int u = ub + 8 * i;
+        const double t = tt[i];
+        double w;
+        if constexpr (ORDER == 3) w = fma(fma(fma(c01[i].x, t, c01[i].y), t, c23[i].x), t, c23[i].y);
+        else if constexpr (ORDER == 1) w = fma(c01[i].x, t, c01[i].y);
+        else w = fma(fma(c01[i].x, t, c01[i].y), t, c23[i].x);
+        if (u < cnt && jok) wrow[u * n + j] = w;
+      }
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < cnt * nc; idx += 256) {
-    const int u = idx / nc, cl = idx - u * nc; // neighbouring lanes: neighbouring channels of one output (rows broadcast)
-    const long long A = a.at + (i0 + u) * a.step;
-    const double *x = win + cl * wstride + (int)((A >> 32) - q0);
-    const double *w = wrow + u * n;
-    double sum = 0.0;
+  { // outputs: neighbouring lanes = neighbouring channels of one output (rows broadcast), 16 outputs per pass
+    const int cl = tid & (kPolyiCh - 1);
+    if (cl < nc) {
+      const ChanRef dst = chan_ref(out, c0 + cl);
+      const double *xw = win + cl * wstride;
+      for (int u = tid >> 4; u < cnt; u += 256 / kPolyiCh) {
+        const long long A = a.at + (i0 + u) * a.step;
+        const double *x = xw + (int)((A >> 32) - q0);
+        const double *w = wrow + u * n;
+        double sum = 0.0;
 #pragma unroll 8
-    for (int j = 0; j < n; ++j) sum = fma(w[j], x[j], sum);
-    fifo_put(chan_ref(out, c0 + cl), a.out_abs + i0 + u, sum);
+        for (int j = 0; j < n; ++j) sum = fma(w[j], x[j], sum);
+        fifo_put(dst, a.out_abs + i0 + u, sum);
+      }
+    }
   }
 }
 
