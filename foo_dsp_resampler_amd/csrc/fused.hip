@@ -608,22 +608,47 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
   const FusedBlock fb = a.blk[bl];
   const int cnt = min((int)(fb.i_lo - fb.seam_i0), kSeamOut); // at most ~(n - 1) * L / step + 1 outputs per boundary (host-checked <= 64)
   // (no divisions by run-time values in the loops: thread = (row, column) of every tile it touches)
+  // (all loads of a phase are issued before the first one is waited for: one memory round trip per phase, not one per row --
+  // written as a plain loop the compiler waits for every load before the LDS store behind it, 16 round trips in a row)
   { // windows [tail of B-1 | head of B]: lane k of a 64-lane row, 4 channels per pass
     const int k = tid & 63;
     const double *const tails = a.seam + ((long long)((int)((B - 1) & a.seam_mask) * (a.d.C + 1) + c0) * 2 + 1) * 32;
     const double *const heads = a.seam + ((long long)((int)(B & a.seam_mask) * (a.d.C + 1) + c0) * 2) * 32;
     if (k < 2 * nm1) {
-      for (int cl = tid >> 6; cl < nc; cl += 4)
-        win[cl][k] = k < nm1 ? (B == 0 ? 0.0 : tails[cl * 64 + k]) : heads[cl * 64 + k - nm1];
+      const double *const src = k < nm1 ? tails + k : heads + (k - nm1);
+      const bool zero = k < nm1 && B == 0;
+      double t[kSeamC / 4];
+#pragma unroll
+      for (int i = 0; i < kSeamC / 4; ++i) {
+        const int cl = min((tid >> 6) + 4 * i, nc - 1);
+        t[i] = zero ? 0.0 : src[cl * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < kSeamC / 4; ++i) {
+        const int cl = (tid >> 6) + 4 * i;
+        if (cl < nc) win[cl][k] = t[i];
+      }
     }
   }
   { // coefficient rows of the boundary's outputs: lane j of a 32-lane row, 8 outputs per pass
-    const int j = tid & 31;
-    for (int u = tid >> 5; u < cnt; u += 8) {
-      const unsigned t = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
-      const unsigned q = t / (unsigned)pl, ph = t - q * (unsigned)pl;
-      if (j < n) cfs[u][j] = a.tab[(long long)ph * n + j];
-      if (j == 0) qs[u] = fb.seam_q0 + (int)q; // window start inside [tail | head], 0 <= . < n-1
+    const int j = min(tid & 31, n - 1);
+    double t[kSeamOut / 8];
+    int q[kSeamOut / 8];
+#pragma unroll
+    for (int i = 0; i < kSeamOut / 8; ++i) {
+      const int u = min((tid >> 5) + 8 * i, max(cnt - 1, 0));
+      const unsigned tc = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
+      const unsigned qq = tc / (unsigned)pl, ph = tc - qq * (unsigned)pl;
+      q[i] = fb.seam_q0 + (int)qq; // window start inside [tail | head], 0 <= . < n-1
+      t[i] = a.tab[(long long)ph * n + j];
+    }
+#pragma unroll
+    for (int i = 0; i < kSeamOut / 8; ++i) {
+      const int u = (tid >> 5) + 8 * i;
+      if (u < cnt) {
+        if ((tid & 31) < n) cfs[u][j] = t[i];
+        if ((tid & 31) == 0) qs[u] = q[i];
+      }
     }
   }
   __syncthreads();

@@ -317,7 +317,14 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_kernel(AnyView 
   const long long q0 = ORDER == 0 ? A0 / a.L : (A0 >> 32);
   const long long q1 = ORDER == 0 ? A1 / a.L : (A1 >> 32);
   const int wlen = (int)(q1 - q0) + a.n;
-  for (int i = tid; i < wlen; i += 256) win[i] = fifo_get(src, a.rd + q0 + i);
+  for (int ib = tid; ib < wlen; ib += 256 * 4) { // 4 loads in flight per thread (a plain loop waits for each before its LDS store)
+    double t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = fifo_get(src, a.rd + q0 + min(ib + 256 * j, wlen - 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ib + 256 * j < wlen) win[ib + 256 * j] = t[j];
+  }
   // rational stage: the whole coefficient table rides in LDS behind the window when it fits (a.tab_lds)
   const double *__restrict__ tab = a.tab;
   if (ORDER == 0 && a.tab_lds) {
@@ -383,7 +390,14 @@ template <int ORDER> __global__ __launch_bounds__(256) void poly_coop_kernel(Any
   const long long A0 = a.at + i0 * a.step, A1 = a.at + (i0 + cnt - 1) * a.step;
   const long long q0 = A0 >> 32, q1 = A1 >> 32;
   const int wlen = (int)(q1 - q0) + a.n;
-  for (int i = tid; i < wlen; i += 256) win[i] = fifo_get(src, a.rd + q0 + i);
+  for (int ib = tid; ib < wlen; ib += 256 * 4) { // 4 loads in flight per thread (a plain loop waits for each before its LDS store)
+    double t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = fifo_get(src, a.rd + q0 + min(ib + 256 * j, wlen - 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ib + 256 * j < wlen) win[ib + 256 * j] = t[j];
+  }
   __syncthreads();
 
   const int sub = tid & 7, tpl = a.n >> 3; // lane within its output's group of 8; taps per lane
@@ -535,7 +549,19 @@ template <int NC> __global__ __launch_bounds__(256) void half_kernel(AnyView in,
   constexpr int reach = 2 * NC - 1;                        // farthest tap from the centre
   const long long w0 = a.rd + a.pre + 2 * i0 - reach - 1;  // window start: centre of output 0 sits at w0 + reach + 1 (even)
   const int wlen = 2 * cnt + 2 * reach + 1;
-  for (int i = tid; i < 2 * (kHalfTile + 32); i += 256) plane[i & 1][i >> 1] = i < wlen ? fifo_get(src, w0 + i) : 0.0;
+  for (int ib = tid; ib < 2 * (kHalfTile + 32); ib += 256 * 6) { // 6 loads in flight per thread, 3 batches
+    double t[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int i = ib + 256 * j;
+      t[j] = i < wlen ? fifo_get(src, w0 + i) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int i = ib + 256 * j;
+      if (i < 2 * (kHalfTile + 32)) plane[i & 1][i >> 1] = t[j];
+    }
+  }
   __syncthreads();
   // centre of output u: even plane [u + NC]; its taps -+(2k+1): odd plane [u + NC - 1 - k] and [u + NC + k]
   for (int u4 = 4 * tid; u4 < cnt; u4 += 4 * 256) {

@@ -35,10 +35,32 @@ template <int KS> __global__ __launch_bounds__(256, KS <= 8 ? 4 : 3) void polymf
   { // stage the window; positions the producer has not written yet read as zero (only unstored outputs see them)
     const PairSpan sp = b0 + W <= a.in_limit ? pair_span(in, pair, hasb, b0, W, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
     if (sp.kind) {
-      for (int i = tid; i < W; i += 256) {
-        double x, y;
-        sp.get(i, x, y);
-        smp[i] = make_double2(x, y);
+      // batches of 5 loads per thread in flight (W <= 2048 + 36 + 4: two batches): as a plain loop the compiler waits for
+      // every load before the LDS store behind it -- nine memory round trips in a row, most of a workgroup's lifetime
+      for (int ib = tid; ib < W; ib += 256 * 5) {
+        double x[5], y[5];
+        if (sp.kind == 1) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const float2 f = sp.p2[min(ib + 256 * j, W - 1) * sp.fstride];
+            x[j] = (double)f.x;
+            y[j] = (double)f.y;
+          }
+        } else { // (pb == pa when the pair has one channel: every load is unconditional)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int i = min(ib + 256 * j, W - 1);
+            x[j] = sp.pa[i];
+            y[j] = sp.pb[i];
+          }
+          if (!hasb) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) y[j] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (ib + 256 * j < W) smp[ib + 256 * j] = make_double2(x[j], y[j]);
       }
     } else {
       const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
