@@ -116,6 +116,31 @@ struct PairSpan {
   }
 };
 
+// NPTS samples i0, i0 + istride, ... of a contiguous span (kind 1 or 2) into registers, every load issued before any is
+// waited for.  (PairSpan::get in an unrolled loop keeps its kind / hasb tests per element, and the compiler then waits for
+// each element's loads at the joins: 8-16 memory round trips in a row at the head of a workgroup.)
+template <int NPTS, typename CT> __device__ __forceinline__ void span_load(const PairSpan &sp, int i0, int istride, CT (&dst)[NPTS])
+{
+  if (sp.kind == 1) {
+#pragma unroll
+    for (int s = 0; s < NPTS; ++s) {
+      const float2 f = sp.p2[(i0 + s * istride) * sp.fstride];
+      dst[s].x = (double)f.x;
+      dst[s].y = (double)f.y;
+    }
+  } else { // (pair_span sets pb = pa for a one-channel pair: both loads are unconditional)
+#pragma unroll
+    for (int s = 0; s < NPTS; ++s) {
+      dst[s].x = sp.pa[i0 + s * istride];
+      dst[s].y = sp.pb[i0 + s * istride];
+    }
+    if (!sp.hasb) {
+#pragma unroll
+      for (int s = 0; s < NPTS; ++s) dst[s].y = 0.0;
+    }
+  }
+}
+
 __device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len, int ca = -1)
 {
   if (ca < 0) ca = 2 * pair; // (pair_channels: differs only with an odd channel count per stream, where float frames are never contiguous pairs)

@@ -169,8 +169,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
         } else {
           const PairSpan sp = in.is_f32 ? PairSpan{0, nullptr, 1, nullptr, nullptr, hasb} : pair_span(in, pair, hasb, e0, P, ca);
           if (sp.kind) { // planar fp64 rings (the producer is another stage), block contiguous in both
-#pragma unroll
-            for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
+            span_load<16>(sp, tid, TF, v);
           } else {
             const ChanRef ia = chan_ref(in, ca), ib = chan_ref(in, hasb ? cb : ca);
 #pragma unroll

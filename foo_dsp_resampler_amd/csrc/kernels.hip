@@ -91,8 +91,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
       const long long base = B * a.q;
       const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
       if (sp.kind) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) sp.get(tid + s * T8, u8[s].x, u8[s].y);
+        span_load<8>(sp, tid, T8, u8);
       } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -109,8 +108,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
       const long long base = B * a.q;
       const PairSpan sp = base + P <= a.in_limit ? pair_span(in, pair, hasb, base, P, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
       if (sp.kind) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) sp.get(tid + s * TF, v[s].x, v[s].y);
+        span_load<16>(sp, tid, TF, v);
       } else {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
