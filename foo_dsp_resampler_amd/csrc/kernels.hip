@@ -262,7 +262,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
   }
 
   const bool inv_active = tid < TD;
-  fft_regs<LOG2ND, +1, XMODE>(v, tid, inv_active, a.tw_inv, lds);
+  // twiddles of the next pass loaded ahead of each exchange where the registers allow it (not at the 16384-point instance's
+  // 128-VGPR cap: 10 -> 36 spilled VGPRs)
+  fft_regs<LOG2ND, +1, XMODE, (LOG2N <= 13 ? 8 : 0)>(v, tid, inv_active, a.tw_inv, lds);
 
   if (inv_active) {
     const ChanRef oa = chan_ref(out, ca), ob = chan_ref(out, hasb ? cb : ca);
