@@ -122,6 +122,40 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
       const long long U = B * a.V;
       const long long j0 = (U - a.c0 + a.L - 1) / a.L;
       const int remL = (int)(j0 * a.L + a.c0 - U);
+      // slot d = remL + L q holds input j0 + q; everything else is a stuffed zero
+      const int nin = (N - remL + a.L - 1) / a.L; // inputs the block touches
+      const PairSpan sp = j0 + nin <= a.in_limit ? pair_span(in, pair, hasb, j0, nin, ca) : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
+      if (sp.kind) {
+        // contiguous inputs: one unconditional (clamped) load per slot, all issued before the first is used, the quotient by a
+        // multiply (d < 2^32 / L).  The element-wise path below costs a division and a memory round trip per slot.
+        const unsigned magic = 0xffffffffu / (unsigned)a.L + 1u;
+        int q[16];
+        bool take[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int d = tid + s * TF - remL;
+          const int qq = (int)__umulhi((unsigned)max(d, 0), magic);
+          take[s] = d >= 0 && qq * a.L == d;
+          q[s] = take[s] ? qq : 0;
+        }
+        if (sp.kind == 1) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const float2 f = sp.p2[q[s] * sp.fstride];
+            v[s] = {(double)f.x, (double)f.y};
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) v[s] = {sp.pa[q[s]], sp.pb[q[s]]};
+          if (!hasb) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) v[s].y = 0.0;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          if (!take[s]) v[s] = {0.0, 0.0};
+      } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int d = tid + s * TF - remL;
@@ -133,6 +167,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
             v[s].y = hasb ? fifo_get(ib, e) : 0.0;
           }
         }
+      }
       }
     }
   }
@@ -284,14 +319,23 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
         }
       }
     } else { // time-domain decimation (dft_filter.h:148-154): keep filtered samples Y with Y % M == 0
-      const long long Y0 = B * a.V;
+      // kept sample Y = Y0 + n is output Y / M: one 64-bit division per workgroup (Y0), per sample a multiply (n + r0 < 2^32 / M)
+      const long long Y0 = B * a.V, ob0 = Y0 / a.M;
+      const int r0 = (int)(Y0 - ob0 * a.M);
+      const unsigned magic = 0xffffffffu / (unsigned)a.M + 1u;
+      const long long o_first = ob0 + (r0 ? 1 : 0);                    // first output of the block
+      const int cnt = (int)((Y0 + a.V - 1) / a.M - o_first) + 1;       // outputs of the block (V >= M)
+      const PairSpan so = (o_first >= a.clip_lo && o_first + cnt <= a.clip_hi) ? pair_span(out, pair, hasb, a.out_offset + o_first, cnt, ca)
+                                                                         : PairSpan{0, nullptr, 1, nullptr, nullptr, hasb};
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int n = tid + s * TD;
-        const long long Y = Y0 + n;
-        if (n < a.V && Y % a.M == 0) {
-          const long long o = Y / a.M;
-          if (o >= a.clip_lo && o < a.clip_hi) {
+        const unsigned t = (unsigned)(n + r0);
+        const int qq = (int)__umulhi(t, magic);
+        if (n < a.V && (unsigned)qq * (unsigned)a.M == t) {
+          const long long o = ob0 + qq;
+          if (so.kind) so.put((int)(o - o_first), v[s].x, v[s].y);
+          else if (o >= a.clip_lo && o < a.clip_hi) {
             fifo_put(oa, a.out_offset + o, v[s].x);
             if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
           }
