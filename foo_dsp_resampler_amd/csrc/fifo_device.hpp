@@ -65,6 +65,34 @@ __device__ __forceinline__ void fifo_put(const ChanRef &r, long long a, double v
 }
 
 
+// `len` consecutive samples of ONE channel starting at absolute index a0, when they lie contiguously in one buffer:
+// kind 1 = float32 frames (element i at p32[i * stride32]), kind 2 = the channel's fp64 ring, kind 0 = split (fifo_get).
+struct ChanSpan {
+  int kind;
+  const float *p32;
+  long long stride32;
+  const double *p64;
+};
+__device__ __forceinline__ ChanSpan chan_span(const AnyView &v, int c, long long a0, long long len)
+{
+  ChanSpan r = {0, nullptr, 1, nullptr};
+  if (v.is_f32) {
+    const int s = c / v.f.nch, ch = c - s * v.f.nch;
+    r.stride32 = v.f.nch;
+    if (v.f.ext && a0 >= v.f.ext_begin && a0 + len <= v.f.ext_end) {
+      r.kind = 1;
+      r.p32 = v.f.ext + s * v.f.ext_stream_stride + (a0 - v.f.ext_begin) * v.f.nch + ch;
+    } else if ((!v.f.ext || a0 + len <= v.f.ext_begin || a0 >= v.f.ext_end) && a0 >= 0 && (a0 & v.f.ring_mask) + len <= v.f.ring_mask + 1) {
+      r.kind = 1;
+      r.p32 = v.f.ring + s * v.f.ring_stream_stride + (a0 & v.f.ring_mask) * v.f.nch + ch;
+    }
+  } else if (a0 >= 0 && (a0 & v.d.mask) + len <= v.d.mask + 1) {
+    r.kind = 2;
+    r.p64 = v.d.ring + (long long)c * v.d.chan_stride + (a0 & v.d.mask);
+  }
+  return r;
+}
+
 // Channel pair -> channels.  nchs = 0: pairs run over all C channels of the handle (2p, 2p+1; the last one may be single).
 // nchs > 0 (batch handles with an odd channel count per stream): pairs never straddle two streams -- every stream has
 // (nchs + 1) / 2 of them and its last channel rides alone with a zero imaginary part, exactly as in a one-stream handle,

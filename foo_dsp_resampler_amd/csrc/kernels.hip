@@ -593,17 +593,26 @@ template <int NC> __global__ __launch_bounds__(256) void half_kernel(AnyView in,
   constexpr int reach = 2 * NC - 1;                        // farthest tap from the centre
   const long long w0 = a.rd + a.pre + 2 * i0 - reach - 1;  // window start: centre of output 0 sits at w0 + reach + 1 (even)
   const int wlen = 2 * cnt + 2 * reach + 1;
-  for (int ib = tid; ib < 2 * (kHalfTile + 32); ib += 256 * 6) { // 6 loads in flight per thread, 3 batches
+  // window into the two parity planes, 6 loads in flight per thread and 3 batches.  With the window contiguous in one buffer
+  // (chan_span) the loads are plain and unconditional; fifo_get's ring / caller-buffer test per element would put every
+  // load behind a branch and a wait of its own (17 memory round trips in a row).
+  const ChanSpan cs = chan_span(in, c, w0, wlen);
+  for (int ib = tid; ib < 2 * (kHalfTile + 32); ib += 256 * 6) {
     double t[6];
+    if (cs.kind == 1) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int i = ib + 256 * j;
-      t[j] = i < wlen ? fifo_get(src, w0 + i) : 0.0;
+      for (int j = 0; j < 6; ++j) t[j] = (double)cs.p32[min(ib + 256 * j, wlen - 1) * cs.stride32];
+    } else if (cs.kind == 2) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t[j] = cs.p64[min(ib + 256 * j, wlen - 1)];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t[j] = ib + 256 * j < wlen ? fifo_get(src, w0 + ib + 256 * j) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int i = ib + 256 * j;
-      if (i < 2 * (kHalfTile + 32)) plane[i & 1][i >> 1] = t[j];
+      if (i < 2 * (kHalfTile + 32)) plane[i & 1][i >> 1] = i < wlen ? t[j] : 0.0;
     }
   }
   __syncthreads();
