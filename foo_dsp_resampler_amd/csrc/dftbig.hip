@@ -49,11 +49,15 @@ __global__ __launch_bounds__(256) void big_cols_fwd_kernel(AnyView in, BigDftArg
   c64 v[16];
   if (a.fdomain_in) { // L = 1, or x2 / x4 in the frequency domain: the block is Mp*16 consecutive stage inputs
     const long long base = B * a.d.q;
+    const PairSpan sp = pair_span(in, pair, hasb, base, 16LL * Mp, ca);
+    if (sp.kind) span_load<16>(sp, n2, Mp, v); // the column's 16 loads issued together
+    else {
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const long long e = base + (long long)n1 * Mp + n2;
-      v[n1].x = fifo_get(ia, e);
-      v[n1].y = hasb ? fifo_get(ib, e) : 0.0;
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const long long e = base + (long long)n1 * Mp + n2;
+        v[n1].x = fifo_get(ia, e);
+        v[n1].y = hasb ? fifo_get(ib, e) : 0.0;
+      }
     }
   } else { // time-domain zero stuffing (dft_filter.h:109-115) in absolute coordinates, as in dft_kernel
     const long long U = B * a.d.V;
