@@ -149,6 +149,11 @@ constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) 
 #ifndef RSMP_EXP_TWLOAD
 #define RSMP_EXP_TWLOAD 0
 #endif
+// timing experiment only (WRONG results): every twiddle load reads entry k = 0 of its row (one line per row: the loads stay,
+// their misses and most of their latency go) -- upper bound of what twiddle tables in LDS could buy
+#ifndef RSMP_EXP_TWK0
+#define RSMP_EXP_TWK0 0
+#endif
 #ifndef RSMP_EXP_NOBAR
 #define RSMP_EXP_NOBAR 0
 #endif
@@ -254,7 +259,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
       for (int r = 0; r < R; ++r) b[r] = v[t + NB * r];
       if (NS > 1 && TWGEN && R == 16) {
-        const int k = (tid + t * T) & (NS - 1);
+        const int k = RSMP_EXP_TWK0 ? 0 : (tid + t * T) & (NS - 1);
         c64 w[16];
 #pragma unroll
         for (int r = 1; r < 16; r <<= 1) {
@@ -283,7 +288,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
         for (int m = 1; m < 8; ++m) apply(8 + m, cmul(w[8], w[m]));
       } else if (NS > 1) {
-        const int k = (tid + t * T) & (NS - 1);
+        const int k = RSMP_EXP_TWK0 ? 0 : (tid + t * T) & (NS - 1);
 #pragma unroll
         for (int r = 1; r < R; ++r) {
           // RSMP_EXP_TWLOAD (timing experiment only, WRONG results): load the twiddles of r = 1, 2, 4, 8 only
@@ -299,7 +304,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
   }
   if (!LAST) {
     if (PF > 0 && active) {
-      const int kn = tid & (NSN - 1);
+      const int kn = RSMP_EXP_TWK0 ? 0 : tid & (NSN - 1);
 #pragma unroll
       for (int r = 1; r <= (TWGEN ? 8 : PF); ++r)
         if (!((RSMP_EXP_TWLOAD || TWGEN) && (r & (r - 1))) && !(TWGEN && RSMP_TWGEN_SQ && r > 1)) wnext[r - 1] = twn[(r - 1) * NSN + kn];
@@ -361,7 +366,7 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
 #pragma unroll
     for (int r = 0; r < R; ++r) b[r] = u[t + NB * r];
     if (NS > 1 && TWGEN && R >= 4) { // w^1, w^2 (, w^4) loaded, the rest multiplied up (see fft_pass)
-      const int k = (tid + t * T8) & (NS - 1);
+      const int k = RSMP_EXP_TWK0 ? 0 : (tid + t * T8) & (NS - 1);
       c64 w[8];
 #pragma unroll
       for (int r = 1; r < R; r <<= 1) {
@@ -381,7 +386,7 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
 #pragma unroll
       for (int r = 1; r < R; ++r) b[r] = DIR > 0 ? cmul(b[r], w[r]) : cmulc(b[r], w[r]);
     } else if (NS > 1) {
-      const int k = (tid + t * T8) & (NS - 1);
+      const int k = RSMP_EXP_TWK0 ? 0 : (tid + t * T8) & (NS - 1);
 #pragma unroll
       for (int r = 1; r < R; ++r) {
         const int rr = (RSMP_EXP_TWLOAD && (r & (r - 1))) ? 1 : r;
