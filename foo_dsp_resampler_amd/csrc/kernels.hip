@@ -319,6 +319,21 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
         }
       }
     } else { // time-domain decimation (dft_filter.h:148-154): keep filtered samples Y with Y % M == 0
+      if constexpr (LOG2N >= 14) { // (the 16384-point instances have no registers to spare: the plain form)
+        const long long Y0 = B * a.V;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int n = tid + s * TD;
+          const long long Y = Y0 + n;
+          if (n < a.V && Y % a.M == 0) {
+            const long long o = Y / a.M;
+            if (o >= a.clip_lo && o < a.clip_hi) {
+              fifo_put(oa, a.out_offset + o, v[s].x);
+              if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
+            }
+          }
+        }
+      } else {
       // kept sample Y = Y0 + n is output Y / M: one 64-bit division per workgroup (Y0), per sample a multiply (n + r0 < 2^32 / M)
       const long long Y0 = B * a.V, ob0 = Y0 / a.M;
       const int r0 = (int)(Y0 - ob0 * a.M);
@@ -340,6 +355,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N == 13 && LOG2ND == 13) ? 
             if (hasb) fifo_put(ob, a.out_offset + o, v[s].y);
           }
         }
+      }
       }
     }
   }
