@@ -18,10 +18,9 @@ extern "C" {
 
 /* Generalises RR_open (rate/ratelib.h:74) to nstreams lock-stepped streams. RR_push/RR_pull/RR_flow
  * on such a handle use packed host buffers (stride = the frame count of the call).
- * Streams never mix audibly, and with an even channel count each stream's output is bit-identical to what a
- * handle of its own produces.  With an odd channel count two neighbouring streams share one complex transform
- * (channels are paired in memory order), so a stream's fp64 rounding -- not its signal -- depends on its
- * neighbour: outputs stay within the 1-ulp float32 parity bar but are not bit-identical to a separate handle. */
+ * Every stream's output is bit-identical to what a handle of its own produces, for even and odd channel counts
+ * alike: the channel pairs that share a complex transform never straddle two streams (with an odd count the last
+ * channel of each stream rides alone, exactly as in a one-stream handle). */
 int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle);
 
 /* Device-pointer forms of RR_push / RR_pull / RR_flow (rate/ratelib.h:75-77).  Pointers are HBM
