@@ -965,6 +965,24 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
             io.in_stream_stride = ein.stride_floats;
             io.out_stream_stride = eout.stride_floats;
             io.nch = nch_;
+          } else if (fu.cfm && s32 && !dst_f32 && !(nch_ & 1) && ein.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
+                     !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(ein.stride_floats & 1)) {
+            // the polyphase stage feeds another stage: same lean kernel, its outputs into the next fifo's fp64 ring (any ring
+            // position: the kernel masks the index), so only the input side limits the range
+            const long long P = 1LL << pend_log2p, q = fa.d.q;
+            const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
+            f0 = 0;
+            f1 = int(std::max<long long>(0, std::min<long long>(pend.nblocks, hi)));
+            io.in = ein.ptr;
+            io.in_ring = static_cast<const float *>(rings_[0].buf);
+            io.in_ring_mask = rings_[0].cap - 1;
+            io.in_ring_stream_stride = rings_[0].cap * nch_;
+            io.in_abs0 = ein.begin;
+            io.in_stream_stride = ein.stride_floats;
+            io.nch = nch_;
+            io.out64 = static_cast<double *>(rings_[i + 1].buf);
+            io.out64_mask = rings_[i + 1].cap - 1;
+            io.out64_chan_stride = rings_[i + 1].cap;
           }
           auto launch_range = [&](int b0, int b1, bool fast) -> int {
             if (b0 >= b1) return kOk;

@@ -80,7 +80,9 @@ constexpr int kPad = 32;
 constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 } // namespace
 
-template <int LOG2P, int KS>
+// OUT64: the outputs go to the planar fp64 ring of the next stage's fifo (absolute index & mask: a ring wrap costs nothing)
+// instead of interleaved float frames -- chains like 44.1k->192k, whose x2 -> 80/147 pair feeds an x4 stage.
+template <int LOG2P, int KS, bool OUT64>
 __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
 {
   constexpr int LOG2N = 12, N = 1 << LOG2N, P = 1 << LOG2P;
@@ -235,7 +237,17 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   const int pl = a.polyL, step = a.step;
   const int irel_hi = fb.irel_lo + fb.cnt;
   const int frame_bytes = io.nch * 4;
-  char *const obytes = reinterpret_cast<char *>(io.out + strm * io.out_stream_stride + (a.out_offset2 + fb.i_lo - io.out_abs0) * io.nch + 2 * pin);
+  char *const obytes = OUT64 ? nullptr
+                            : reinterpret_cast<char *>(io.out + strm * io.out_stream_stride + (a.out_offset2 + fb.i_lo - io.out_abs0) * io.nch + 2 * pin);
+  // OUT64: one descriptor per channel over its whole ring; output ib of the block sits at ring slot (o64 + ib) & mask
+  const unsigned o64 = OUT64 ? (unsigned)((a.out_offset2 + fb.i_lo) & io.out64_mask) : 0u;
+  const unsigned m64 = (unsigned)io.out64_mask;
+  __amdgpu_buffer_rsrc_t orsrcA, orsrcB;
+  if constexpr (OUT64) {
+    double *ra = io.out64 + (long long)(2 * pair) * io.out64_chan_stride;
+    orsrcA = __builtin_amdgcn_make_buffer_rsrc(ra, 0, (int)((io.out64_mask + 1) * 8), 0x00020000);
+    orsrcB = __builtin_amdgcn_make_buffer_rsrc(ra + io.out64_chan_stride, 0, (int)((io.out64_mask + 1) * 8), 0x00020000);
+  }
   const int rloc = 4 * bq + hi; // this lane's output residue within a 16-residue group
   const int ngrp = a.NGRP;
   const double2 *const cfm_lane = a.cfm2 + lane;
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #if RSMP_BUFSTORE
     // raw buffer over this round's outputs [0, cnt) of the block: frame ib at byte ib * frame_bytes, 8 bytes of it are ours
     const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc(obytes, 0, cnt > 0 ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(obytes, 0, (!OUT64 && cnt > 0) ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
 #endif
     const int step4 = 4 * step, pl4 = 4 * pl;
 
@@ -310,6 +322,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       for (int s = 3; s < KS; ++s) { accA += xc[s].x * 1e-30; accB += cc[s] * 1e-30 + xc[s].y * 1e-30; } // keep the loads alive
 #endif
       const int ib = lane_ib + 16 * g + c * pl4;
+      if constexpr (OUT64) {
+        // (the descriptor spans the ring, so the block's range test is explicit here; lanes that fail it get an offset
+        // behind the ring and the hardware drops their stores)
+        const bool ok = (unsigned)ib < (unsigned)cnt && 16 * g + rloc < pl;
+        const unsigned off = ok ? ((o64 + (unsigned)ib) & m64) * 8u : 0xffffffffu;
+        const rsmp_v2u da = {(unsigned)__double2loint(accA), (unsigned)__double2hiint(accA)};
+        const rsmp_v2u db = {(unsigned)__double2loint(accB), (unsigned)__double2hiint(accB)};
+        __builtin_amdgcn_raw_buffer_store_b64(da, orsrcA, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(db, orsrcB, (int)off, 0, 0);
+      } else
 #if RSMP_BUFSTORE
       {
         // one unconditional buffer store per tile: outputs in front of the block (ib < 0 wraps to a huge offset) and behind
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #undef RSMP_STAMP
 }
 
-template <int LOG2P, int KS> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
+template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
   constexpr int N = 4096;
   size_t lds_bytes = 8 * size_t(fft_lds_doubles_halves(12));
@@ -373,7 +395,7 @@ template <int LOG2P, int KS> static hipError_t launch_fast_t(const FusedArgs &a,
   lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
   static std::atomic<bool> attr_done{false};
   if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_fast_kernel<LOG2P, KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_fast_kernel<LOG2P, KS, OUT64>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
     if (e != hipSuccess) return e;
     attr_done.store(true, std::memory_order_release);
@@ -381,7 +403,7 @@ template <int LOG2P, int KS> static hipError_t launch_fast_t(const FusedArgs &a,
   FusedArgs b = a;
   b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
   dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(N / 16);
-  hipLaunchKernelGGL((fused_fast_kernel<LOG2P, KS>), grid, block, lds_bytes, st, b, io);
+  hipLaunchKernelGGL((fused_fast_kernel<LOG2P, KS, OUT64>), grid, block, lds_bytes, st, b, io);
   return hipGetLastError();
 }
 
@@ -391,10 +413,10 @@ bool fused_fast_supported(int log2n, int log2p, int ksteps)
   return !off && log2n == 12 && (log2p == 11 || log2p == 12) && (ksteps == 7 || ksteps == 8);
 }
 
-#define RSMP_FAST_CASE(p, ks)                                                  \
-  if (log2p == p && a.KS == ks) {                                              \
-    if (kname) *kname = "rsmp::fused_fast_kernel<" #p ", " #ks ">";            \
-    return launch_fast_t<p, ks>(a, io, st);                                    \
+#define RSMP_FAST_CASE(p, ks)                                                                        \
+  if (log2p == p && a.KS == ks) {                                                                    \
+    if (kname) *kname = io.out64 ? "rsmp::fused_fast_kernel<" #p ", " #ks ", true>" : "rsmp::fused_fast_kernel<" #p ", " #ks ", false>"; \
+    return io.out64 ? launch_fast_t<p, ks, true>(a, io, st) : launch_fast_t<p, ks, false>(a, io, st); \
   }
 
 hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)

@@ -177,6 +177,9 @@ struct FastIo {
   long long in_abs0, out_abs0;
   long long in_stream_stride, out_stream_stride; // floats between streams
   int nch;                    // channels per stream (even)
+  // OUT64 instances (the polyphase stage feeds another stage): planar fp64 ring of the destination fifo instead of `out`
+  double *out64;              // ring of channel 0
+  long long out64_mask, out64_chan_stride; // items - 1, items between channels
 };
 bool fused_fast_supported(int log2n, int log2p, int ksteps);
 hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);

@@ -181,7 +181,7 @@ def test_profile_report_names_the_kernels_the_dispatch_picked():
     r.flow_device(x, 60000, y, 140000)
     rep = r.profile_report()
     names = {k["kernel"] for k in rep}
-    assert "rsmp::fused_fast_kernel<11, 7>" in names and "rsmp::seam_kernel" in names, names
+    assert "rsmp::fused_fast_kernel<11, 7, false>" in names and "rsmp::seam_kernel" in names, names
     assert all(k["launches"] >= 1 and k["ms"] > 0 for k in rep)
     r.push(x.cpu().numpy())                                         # host path: output into the ring -> generic kernel
     names = {k["kernel"] for k in r.profile_report()}
