@@ -166,6 +166,9 @@ def main():
         backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            probe = torch.zeros(1, device="cuda")
+            dist.all_reduce(probe)  # the communicator is created here, not inside the timed region
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
