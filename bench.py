@@ -10,6 +10,10 @@
   3  96k   -> 44.1k 32 ch, aliasing off, linear phase, 16 streams per GPU
   4  1024 independent stereo 44.1k -> 48k streams, sharded over the ranks (`--gpus N`: 1024/N streams each)
 
+Launching: `python bench.py --gpus N` starts N ranks itself (one fresh child process per GPU, started by a parent that has
+made no GPU call and never re-execs; rendezvous on 127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N` (WORLD_SIZE already set) it is one of the ranks.  Either way rank 0 prints the one JSON line.
+
 One "step" = one pass of the hot path over one batch of synthetic input: every rank pushes P frames of its S
 independent streams (already resident in HBM) through RRX_flow_device and gets the resampled frames written to an
 HBM output buffer.  Streams are independent (rate_base.h:533-540), so N GPUs = N shards of streams with no
@@ -134,6 +138,72 @@ def lookup_traffic(config, streams, frames, kernels):
     return total
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N children of this script, one rank per GPU.  The parent makes no
+    GPU call (counting devices does not initialise the runtime on this image), never execs, and exits with the worst
+    child's code; the children inherit stdout, so rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    if not os.environ.get("BENCH_SHARE_GPU"):
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: this node has %d GPU(s) (BENCH_SHARE_GPU=1 rehearses the ranks on one)" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.05)
+        if any(p.poll() not in (None, 0) for p in procs):  # a rank died: do not leave the others waiting in a barrier
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def lcg_noise_device(torch, nstreams, frames, nch, first_seed, device):
+    """SURVEY.md 8(d) synthetic input, generated on the GPU: stream k is the LCG s = s*1664525 + 1013904223 (mod 2^32) seeded
+    with first_seed + k, sample = ((s >> 8) - 2^23) / 2^23 * 0.5, interleaved -- bit for bit tests/oracle_binding.lcg_noise
+    (jump-ahead form s_k = a^k s_0 + c (a^(k-1) + ... + 1); int64 products wrap mod 2^64, of which mod 2^32 is a factor)."""
+    n = frames * nch
+    a = torch.full((n,), 1664525, dtype=torch.int64, device=device)
+    ak = torch.cumprod(a, 0)                                                          # a^1 .. a^n
+    ck = torch.cumsum(torch.cat([torch.ones(1, dtype=torch.int64, device=device), ak[:-1]]), 0) * 1013904223
+    out = torch.empty((nstreams, frames, nch), dtype=torch.float32, device=device)
+    for k0 in range(0, nstreams, 16):
+        k1 = min(nstreams, k0 + 16)
+        seeds = (torch.arange(k0, k1, dtype=torch.int64, device=device) + first_seed) & 0xFFFFFFFF
+        vals = (ak[None, :] * seeds[:, None] + ck[None, :]) & 0xFFFFFFFF
+        out[k0:k1] = (((vals >> 8).to(torch.float64) - 8388608.0) / 8388608.0 * 0.5).to(torch.float32).view(k1 - k0, frames, nch)
+    return out
+
+
+def check_against_oracle(cfg, x0, pushes, y_last):
+    """Outside the timed region: the oracle replays stream 0's `pushes` pushes of x0 on the CPU; its output for the last
+    one must be what the GPU wrote for the last timed step (tests/parity.py's bar: 1 ulp, 1e-7 relative RMS)."""
+    from oracle_binding import Oracle
+    from parity import compare_f32
+    o = Oracle(cfg["fi"], cfg["fo"], cfg["nch"], **cfg["kw"])
+    ref = None
+    for _ in range(pushes):
+        o.push(x0)
+        ref = o.pull_all(1 << 20)
+    if ref.shape != y_last.shape:
+        return {"checked": False, "why": "frame count %d, oracle %d" % (y_last.shape[0], ref.shape[0])}
+    rep = compare_f32(y_last, ref)
+    ok = rep["max_ulp"] <= 1 and rep["rel_rms"] <= 1e-7
+    return {"checked": bool(ok), "check": {"what": "stream 0, output of timed step %d (push %d since open) vs oracle/rate_oracle.c" % (pushes, pushes),
+                                           "frames": int(ref.shape[0]), "max_ulp": float(rep["max_ulp"]), "rel_rms": float(rep["rel_rms"])}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +213,12 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="override: independent streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per push (default: isamp_max, rate_base.h:531)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", dest="check", action="store_true", default=True,
+                    help="after the timed region: stream 0 of the last timed step against the CPU oracle (\"checked\": true); default")
+    ap.add_argument("--no-check", dest="check", action="store_false")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     cfg = CONFIGS[args.config]
     fi, fo, nch, kw = cfg["fi"], cfg["fo"], cfg["nch"], cfg["kw"]
     bytes_per_unit = 4.0 * (1.0 + fo / fi)
@@ -154,6 +229,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BENCH_DRY_RUN"):
+        # launch rehearsal (no GPU needed, CPU tests): rendezvous, shard arithmetic and the one-line-from-rank-0 contract,
+        # nothing measured -- "value" is null and the line says so
+        import torch.distributed as dist
+        from foo_dsp_resampler_amd.sharding import shard_range
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        first, n = shard_range(cfg["streams"], world, rank) if cfg.get("total") else (rank * cfg["streams"], cfg["streams"])
+        mine = torch.tensor([rank, local_rank, first, n], dtype=torch.int64)
+        rows = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(rows, mine)
+            dist.barrier()
+        else:
+            rows = [mine]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": "launch rehearsal only: nothing measured", "value": None, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup,
+                              "ranks": [{"rank": int(r[0]), "local_rank": int(r[1]), "first_stream": int(r[2]), "streams": int(r[3])} for r in rows]}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # BENCH_SHARE_GPU=1 / BENCH_BACKEND=gloo: rehearse the multi-rank path on a one-GPU box
@@ -182,8 +281,8 @@ def main():
         S = cfg["streams"]
     r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
     P = min(args.frames or cfg.get("frames") or r.isamp_max, r.isamp_max)
-    g = torch.Generator(device="cuda").manual_seed(12345 + rank)
-    x = torch.rand((S, P, nch), generator=g, device="cuda", dtype=torch.float32) - 0.5
+    first_stream = shard_range(cfg["streams"], world, rank)[0] if strong else rank * S
+    x = lcg_noise_device(torch, S, P, nch, 12345 + first_stream, "cuda")  # LCG noise, seed 12345 + stream id
     cap = int(P * fo / fi) + 8192
     y = torch.empty((S, cap, nch), device="cuda", dtype=torch.float32)
     torch.cuda.synchronize()
@@ -206,14 +305,20 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)
     out_frames = 0
+    last_og = [0]
     for _ in range(args.steps):
-        out_frames += step()
+        last_og[0] = step()
+        out_frames += last_og[0]
     ev1.record(stream)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
+    checked = None
+    if args.check and rank == 0:  # outside the timed region, before anything overwrites y
+        og_last = last_og[0]
+        checked = check_against_oracle(cfg, x[0].cpu().numpy(), args.warmup + args.steps, y[0, :og_last].cpu().numpy())
 
     # second pass of the same K steps with HIP events around every stage launch (profiling keeps all
     # kernels on one stream, so it stays out of the pass that defines `value`)
@@ -289,6 +394,8 @@ def main():
                          "fp64_issue_frac": round(units_per_step_rank * flops_unit / (div_ms / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 5) if div_ms else None,
                          "fp64_peak_tflops": FP64_PEAK_TFLOPS},
         }
+        if checked is not None:
+            out.update(checked)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -4,9 +4,12 @@
 
 #include "engine.hpp"
 
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 struct RR_handle_tag {
   rsmp::Engine *eng;
@@ -16,6 +19,32 @@ namespace {
 
 void (*g_alloc_handler)(void) = nullptr;
 int g_initialized = 0;
+// RATELIB_AMD_DEVICES (read by init_ratelib): devices RR_open / RRX_open_batch deal new handles over, round-robin.
+// Empty = a handle lives on the calling thread's current device.
+std::vector<int> g_devices;
+std::atomic<unsigned> g_next_device{0};
+
+// "all" or a comma list of device indices; false when it names a device the process does not have or that is not gfx950
+bool parse_devices(const char *spec, int count, std::vector<int> &out)
+{
+  out.clear();
+  if (!spec || !*spec) return true;
+  if (std::strcmp(spec, "all") == 0) {
+    for (int d = 0; d < count; ++d) out.push_back(d);
+  } else {
+    for (const char *p = spec; *p;) {
+      char *end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p || d < 0 || d >= count) return false;
+      out.push_back(int(d));
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') return false;
+    }
+  }
+  for (int d : out)
+    if (!rsmp::device_is_gfx950(d)) return false;
+  return true;
+}
 
 rsmp::Config to_config(const RR_config *c)
 {
@@ -40,9 +69,11 @@ int finish(int rc)
 // No C++ exception of ours may cross the C ABI: host-side containers can throw std::bad_alloc, which is
 // reported like any other allocation failure (the handler itself may throw, as the plugin's does; that is the
 // caller's contract, rate/xmalloc.c:38-43).
-template <class Fn> int guarded(Fn fn)
+template <class Fn> int guarded(RR_handle *h, Fn fn)
 {
   int rc;
+  rsmp::DeviceScope on(h->eng->device()); // the handle's device, whatever the calling thread has selected
+  if (!on.ok()) return finish(RR_INTERNAL);
   try {
     rc = fn();
   } catch (const std::bad_alloc &) {
@@ -53,7 +84,8 @@ template <class Fn> int guarded(Fn fn)
   return finish(rc);
 }
 
-int open_common(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle)
+// device: -1 = the default placement (RATELIB_AMD_DEVICES round-robin, else the calling thread's current device)
+int open_common(const RR_config *config, int nchannels, int nstreams, int device, RR_handle **const handle)
 {
   if (handle == nullptr) return RR_INVPARAM;
   *handle = nullptr;
@@ -62,9 +94,10 @@ int open_common(const RR_config *config, int nchannels, int nstreams, RR_handle 
   RR_handle *h = new (std::nothrow) RR_handle_tag();
   if (!h) return finish(RR_ENOMEM);
   h->eng = nullptr;
+  if (device < 0 && !g_devices.empty()) device = g_devices[g_next_device.fetch_add(1) % g_devices.size()];
   int rc;
   try {
-    rc = rsmp::Engine::create(to_config(config), nchannels, nstreams, &h->eng);
+    rc = rsmp::Engine::create(to_config(config), nchannels, nstreams, device, &h->eng);
   } catch (const std::bad_alloc &) {
     rc = RR_ENOMEM;
   } catch (...) {
@@ -89,50 +122,63 @@ int init_ratelib(void (*alloc_error_handler)(void))
   g_alloc_handler = alloc_error_handler;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return -1; // no GPU: refuse loudly, there is no CPU path
-  if (!rsmp::device_is_gfx950()) return -1;                    // the code object is gfx950-only: refuse here, not at the first launch
+  if (!parse_devices(std::getenv("RATELIB_AMD_DEVICES"), n, g_devices)) return -1; // names a device we cannot run on
+  if (g_devices.empty() && !rsmp::device_is_gfx950()) return -1; // the code object is gfx950-only: refuse here, not at the first launch
+  (void)rsmp::knobs(); // the environment is read here, once
   g_initialized = 1;
   return 0;
 }
 
 void close_ratelib(void) { g_initialized = 0; }
 
-int RR_open(const RR_config *config, int nchannels, RR_handle **const handle) { return open_common(config, nchannels, 1, handle); }
+int RR_open(const RR_config *config, int nchannels, RR_handle **const handle) { return open_common(config, nchannels, 1, -1, handle); }
 
 int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle)
 {
-  return open_common(config, nchannels, nstreams, handle);
+  return open_common(config, nchannels, nstreams, -1, handle);
 }
+
+int RRX_open_batch_on(const RR_config *config, int nchannels, int nstreams, int device, RR_handle **const handle)
+{
+  if (device < 0) {
+    if (handle) *handle = nullptr;
+    return RR_INVPARAM;
+  }
+  return open_common(config, nchannels, nstreams, device, handle);
+}
+
+int RRX_device(const RR_handle *h) { return h ? h->eng->device() : -1; }
 
 int RR_push(RR_handle *h, const fb_sample_t *ibuf, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->push_host(ibuf, isamp, isamp); });
+  return guarded(h, [&] { return h->eng->push_host(ibuf, isamp, isamp); });
 }
 
 int RR_pull(RR_handle *h, fb_sample_t *obuf, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
   size_t n = osamp < h->eng->available() ? osamp : h->eng->available();
-  return guarded([&] { return h->eng->pull_host(obuf, n, osamp, ogen); });
+  return guarded(h, [&] { return h->eng->pull_host(obuf, n, osamp, ogen); });
 }
 
 int RR_flow(RR_handle *h, const fb_sample_t *ibuf, fb_sample_t *obuf, size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
   if (h->eng->nstreams() != 1) return RR_INVPARAM; // packed layout of a batch is ambiguous here
-  return guarded([&] { return h->eng->flow_host(ibuf, isamp, obuf, osamp, isamp, osamp, iused, ogen); });
+  return guarded(h, [&] { return h->eng->flow_host(ibuf, isamp, obuf, osamp, isamp, osamp, iused, ogen); });
 }
 
 int RR_drain(RR_handle *h)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->drain(); });
+  return guarded(h, [&] { return h->eng->drain(); });
 }
 
 void RR_close(RR_handle **h)
 {
   if (h == nullptr || *h == nullptr) return;
-  delete (*h)->eng;
+  delete (*h)->eng; // (~Engine selects the handle's device for its frees itself)
   delete *h;
   *h = nullptr;
 }
@@ -153,58 +199,57 @@ const char *RR_strerror(int error)
 int RRX_push_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->push_device(d_ibuf, in_stride, isamp); });
+  return guarded(h, [&] { return h->eng->push_device(d_ibuf, in_stride, isamp); });
 }
 
 int RRX_pull_device(RR_handle *h, fb_sample_t *d_obuf, size_t out_stride, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->pull_device(d_obuf, out_stride, osamp, ogen); });
+  return guarded(h, [&] { return h->eng->pull_device(d_obuf, out_stride, osamp, ogen); });
 }
 
 int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, fb_sample_t *d_obuf, size_t out_stride,
                     size_t isamp, size_t osamp, size_t *iused, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->flow_device(d_ibuf, in_stride, d_obuf, out_stride, isamp, osamp, iused, ogen); });
+  return guarded(h, [&] { return h->eng->flow_device(d_ibuf, in_stride, d_obuf, out_stride, isamp, osamp, iused, ogen); });
 }
 
 int RRX_push_strided(RR_handle *h, const fb_sample_t *ibuf, size_t in_stride, size_t isamp)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->push_host(ibuf, in_stride, isamp); });
+  return guarded(h, [&] { return h->eng->push_host(ibuf, in_stride, isamp); });
 }
 
 int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t osamp, size_t *ogen)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->pull_host(obuf, out_stride, osamp, ogen); });
+  return guarded(h, [&] { return h->eng->pull_host(obuf, out_stride, osamp, ogen); });
 }
 
 int RRX_set_stream(RR_handle *h, void *hip_stream)
 {
   if (!h) return RR_NULLHANDLE;
   const bool own = hip_stream == RRX_STREAM_OWN;
-  return guarded([&] { return h->eng->set_stream(own ? nullptr : static_cast<hipStream_t>(hip_stream), own); });
+  return guarded(h, [&] { return h->eng->set_stream(own ? nullptr : static_cast<hipStream_t>(hip_stream), own); });
 }
 
 int RRX_sync(RR_handle *h)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->sync(); });
+  return guarded(h, [&] { return h->eng->sync(); });
 }
 
 int RRX_profile(RR_handle *h, int enable)
 {
   if (!h) return RR_NULLHANDLE;
-  h->eng->set_profiling(enable != 0);
-  return RR_OK;
+  return guarded(h, [&] { h->eng->set_profiling(enable != 0); return int(RR_OK); });
 }
 
 int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, double *other_ms, long long *other_launches)
 {
   if (!h) return RR_NULLHANDLE;
-  return guarded([&] { return h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches); });
+  return guarded(h, [&] { return h->eng->read_profile(hot_ms, hot_launches, other_ms, other_launches); });
 }
 
 int RRX_profile_report(RR_handle *h, char *buf, size_t cap)
@@ -212,7 +257,7 @@ int RRX_profile_report(RR_handle *h, char *buf, size_t cap)
   if (!h) return -RR_NULLHANDLE;
   if (!buf || !cap) return -RR_INVPARAM;
   std::string s;
-  int rc = guarded([&] { return h->eng->read_profile_json(s); });
+  int rc = guarded(h, [&] { return h->eng->read_profile_json(s); });
   if (rc) return -rc;
   size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
   std::memcpy(buf, s.data(), n);

@@ -213,13 +213,8 @@ template <int LOG2M, int LOG2MP, int LOG2MD> static hipError_t launch_rows_t(con
 {
   constexpr int M = 1 << LOG2M;
   constexpr size_t lds_bytes = 8 * size_t(std::max(std::max(fft_lds_doubles(LOG2M), fft_lds_doubles(LOG2MP)), fft_lds_doubles(LOG2MD)));
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&big_rows_kernel<LOG2M, LOG2MP, LOG2MD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_done.store(true, std::memory_order_release);
-  }
+  static DynLdsOnce attr;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&big_rows_kernel<LOG2M, LOG2MP, LOG2MD>), int(lds_bytes)); e != hipSuccess) return e;
   hipLaunchKernelGGL((big_rows_kernel<LOG2M, LOG2MP, LOG2MD>), dim3(16, nitems), dim3(M / 16), lds_bytes, st, a);
   return hipGetLastError();
 }

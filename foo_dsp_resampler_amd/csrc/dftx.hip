@@ -27,9 +27,7 @@
 #include <atomic>
 #include <cstdlib>
 
-#ifndef RSMP_DFTX_SKIP
-#define RSMP_DFTX_SKIP 0 // timing experiments only (WRONG results): 1 = no stores of the first component pair, 2 = of the last
-#endif
+// RSMP_DFTX_SKIP (knobs.hpp; -DRSMP_EXPERIMENTS builds only, WRONG results): 1 = no stores of the first component pair, 2 = of the last
 
 namespace rsmp {
 
@@ -263,13 +261,8 @@ static bool span_contiguous(const AnyView &v, long long a0, long long len, int C
 
 template <int LL, int OKIND> static hipError_t launch_dftx_run(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)
 {
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dftx_kernel<LL, OKIND>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(kXLdsBytes));
-    if (e != hipSuccess) return e;
-    attr_done.store(true, std::memory_order_release);
-  }
+  static DynLdsOnce attr;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&dftx_kernel<LL, OKIND>), int(kXLdsBytes)); e != hipSuccess) return e;
   dim3 grid(item_grid(a.nblocks, a.npairs, a.hp)), block(256);
   hipLaunchKernelGGL((dftx_kernel<LL, OKIND>), grid, block, kXLdsBytes, st, in, out, a);
   return hipGetLastError();
@@ -305,8 +298,7 @@ template <int LL> static hipError_t launch_dftx_t(const AnyView &in, const AnyVi
 // x L in the frequency domain with blocks of L * 2048 points that keep their length
 bool dftx_supported(int log2n, int log2p, int log2nd)
 {
-  static const bool off = getenv("RSMP_NO_DFTX") != nullptr;
-  return !off && log2p == kXP && log2nd == log2n && (log2n == 13 || log2n == 14);
+  return !knobs().no_dftx && log2p == kXP && log2nd == log2n && (log2n == 13 || log2n == 14);
 }
 
 hipError_t launch_dftx(int log2n, bool src_f32, bool dst_f32, const F32View &sf, const F64View &sd, const F32View &df,

@@ -35,12 +35,40 @@ long long next_pow2(long long v) { long long p = 1; while (p < v) p <<= 1; retur
 // host mirror of fft_device.hpp's schedule
 } // namespace
 
-// true when the current device can run this library's code object (built with --offload-arch=gfx950 only)
-bool device_is_gfx950()
+const Knobs &knobs()
 {
-  int dev = 0;
+  static const Knobs k = [] {
+    Knobs r;
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    r.no_fuse = on("RSMP_NO_FUSE");
+    r.no_mfma = on("RSMP_NO_MFMA");
+    r.no_polymf = on("RSMP_NO_POLYMF");
+    r.no_fast = on("RSMP_NO_FAST");
+    r.no_dftx = on("RSMP_NO_DFTX");
+    r.no_polyi = on("RSMP_NO_POLYI");
+    r.no_polycoop = on("RSMP_NO_POLYCOOP");
+    r.spread_vector = on("RSMP_SPREAD_VECTOR");
+    r.no_side = on("RSMP_NO_SIDE");
+    r.no_graph = on("RSMP_NO_GRAPH");
+    r.stamps = on("RSMP_STAMPS");
+    r.occ = on("RSMP_OCC");
+    r.test_hooks = on("RSMP_TEST_HOOKS");
+    if (const char *v = getenv("RSMP_SLAB_MB")) r.slab_mb = atof(v) > 0 ? atof(v) : r.slab_mb;
+    if (const char *v = getenv("RSMP_LDS_PAD")) r.lds_pad = size_t(std::max(0, atoi(v)));
+#ifdef RSMP_EXPERIMENTS
+    if (const char *v = getenv("RSMP_DBG")) r.dbg = atoi(v);
+#endif
+    return r;
+  }();
+  return k;
+}
+
+// true when the current device can run this library's code object (built with --offload-arch=gfx950 only)
+bool device_is_gfx950(int device)
+{
+  int dev = device;
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  if ((dev < 0 && hipGetDevice(&dev) != hipSuccess) || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
@@ -51,14 +79,21 @@ int num_passes(int log2m) { return (log2m + 3) / 4; }
 
 } // namespace
 
-int Engine::create(const Config &cfg, int nch, int nstreams, Engine **out)
+int Engine::create(const Config &cfg, int nch, int nstreams, int device, Engine **out)
 {
   if (!out) return kInvParam;
   *out = nullptr;
   if (nch < 1 || nstreams < 1) return kInvParam;
-  if ((long long)nch * nstreams > INT_MAX / 4096) return kNoMem; // more channels than any device could hold fifos for
+  if ((long long)nch * nstreams > INT_MAX / 4096) return kNoMem; // parameter guard: more channels than any device could hold fifos for
+  int dev_count = 0;
+  if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1) return kUninit; // no HIP device: fail loudly
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return kUninit;
+  if (device >= dev_count) return kInvParam; // a device this process does not have
+  DeviceScope on(device);
+  if (!on.ok()) return kInternal;
   Engine *e = new (std::nothrow) Engine();
   if (!e) return kNoMem;
+  e->device_ = device;
   int rc = e->init(cfg, nch, nstreams);
   if (rc != kOk) {
     delete e;
@@ -70,13 +105,18 @@ int Engine::create(const Config &cfg, int nch, int nstreams, Engine **out)
 
 namespace { std::atomic<int> g_fail_alloc{0}; }
 
-void Engine::fail_alloc_after(int n) { g_fail_alloc.store(n > 0 ? n : 0); }
+// honoured only when the process was started with RSMP_TEST_HOOKS set (knobs.hpp): a production process cannot arm it
+void Engine::fail_alloc_after(int n) { g_fail_alloc.store(knobs().test_hooks && n > 0 ? n : 0); }
 
 // every device allocation of the engine goes through here (RR_ENOMEM mapping, test failpoint)
 int Engine::dev_alloc(void **p, size_t bytes)
 {
   *p = nullptr;
-  if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1) == 1) return kNoMem;
+  for (int cur = g_fail_alloc.load(std::memory_order_relaxed); cur > 0;) // one atomic step per allocation (compare-exchange countdown)
+    if (g_fail_alloc.compare_exchange_weak(cur, cur - 1)) {
+      if (cur == 1) return kNoMem;
+      break;
+    }
   const hipError_t e = hipMalloc(p, bytes);
   if (e == hipSuccess) return kOk;
   (void)hipGetLastError(); // the failure is reported through the return code; do not leave it sticky
@@ -146,9 +186,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   S_ = nstreams;
   C_ = nch * nstreams;
 
-  int dev_count = 0;
-  if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count < 1) return kUninit; // no HIP device: fail loudly
-  if (!device_is_gfx950()) return kUninit; // the code object is built for gfx950 only: refuse here, not at the first launch
+  if (!device_is_gfx950(device_)) return kUninit; // the code object is built for gfx950 only: refuse here, not at the first launch
   HIP_TRY(hipStreamCreateWithFlags(&own_, hipStreamNonBlocking));
   stream_ = own_;
   HIP_TRY(hipEventCreateWithFlags(&ev_switch_, hipEventDisableTiming));
@@ -157,9 +195,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   HIP_TRY(hipEventCreateWithFlags(&ev_seam_[0], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_seam_[1], hipEventDisableTiming));
 
-  dbg_ = getenv("RSMP_DBG") ? atoi(getenv("RSMP_DBG")) : 0;
-  no_side_ = getenv("RSMP_NO_SIDE") != nullptr;
-  if (getenv("RSMP_STAMPS")) {
+  const Knobs &kn = knobs(); // the environment was read once per process; nothing below or on the launch path calls getenv
+  dbg_ = kn.dbg;
+  no_side_ = kn.no_side;
+  if (kn.stamps) {
     ALLOC_TRY(&stamps_, 16 * sizeof(unsigned long long));
     HIP_TRY(hipMemset(stamps_, 0, 16 * sizeof(unsigned long long)));
   }
@@ -265,7 +304,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     const int threads = f.N / 16;
     const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
     if (NG > threads || !fused_shape_supported(log2n, log2p, p.n, p.n + dmax, max_seam)) continue;
-    if (getenv("RSMP_NO_FUSE")) continue;
+    if (kn.no_fuse) continue;
     Fuse &fu = fuse_[i];
     fu.on = true;
     fu.span = p.n + dmax;
@@ -320,12 +359,12 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       // variant (3.90 against 3.74 ms at the time); with the lean kernel's later gains the matrix-pipe variant wins despite
       // its 4-way conflicts: 96k->44.1k 3.26 against 3.74 ms, 48k->44.1k +25 %.  RSMP_SPREAD_VECTOR=1 restores the old choice.)
       bool lanes_spread = true;
-      if (getenv("RSMP_SPREAD_VECTOR"))
+      if (kn.spread_vector)
         for (int j1 = 0; j1 < 4; ++j1)
           for (int j2 = j1 + 1; j2 < 4; ++j2)
             if (((j2 - j1) * pstep) % 16 == 0) lanes_spread = false;
       const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && lanes_spread;
-      if (!getenv("RSMP_NO_MFMA") && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
+      if (!kn.no_mfma && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)
           for (int s = 0; s < KS; ++s)
@@ -390,7 +429,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   for (int i = 0; i < ns; ++i) {
     const StageSpec &p = plan_.stages[i];
     if (p.kind != StageKind::Poly || p.order != 0 || (i > 0 && fuse_[i - 1].on) || p.L < 64) continue;
-    if (getenv("RSMP_NO_MFMA") || getenv("RSMP_NO_POLYMF")) continue;
+    if (kn.no_mfma || kn.no_polymf) continue;
     const int pstep = int(p.step64 >> 32), at0 = int(p.at0 >> 32);
     int d4 = 0;
     for (int rb = 0; rb < p.L; rb += 4) {
@@ -450,7 +489,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
   // Bound the fp64 fifos between stages: a push is cut into time slabs, each slab runs through every stage
   // before the next one starts.  Measured on the 3-stage 44.1k->192k chain (32 streams x 8 ch): 96 MB slabs 15.0,
   // 192 MB 15.5, 400 MB 16.6, 1600 MB 17.3 Gsamples/s -- launch size matters more than Infinity-Cache residency.
-  const double budget = (getenv("RSMP_SLAB_MB") ? atof(getenv("RSMP_SLAB_MB")) : 1536.0) * 1024 * 1024;
+  const double budget = kn.slab_mb * 1024 * 1024;
   slab_frames_ = bytes_per_in_frame > 0 ? size_t(budget / bytes_per_in_frame) : plan_.isamp_max;
   slab_frames_ = std::max<size_t>(slab_frames_, 8192);
   slab_frames_ = std::min<size_t>(slab_frames_, std::max<size_t>(plan_.isamp_max, 1));
@@ -589,7 +628,8 @@ void Engine::free_garbage()
 
 Engine::~Engine()
 {
-  if (stream_) (void)hipStreamSynchronize(stream_);
+  DeviceScope on(device_);
+  (void)hipStreamSynchronize(stream_); // nullptr is the default stream (RRX_set_stream(h, NULL)): it too may hold queued work on our buffers
   if (own_ && own_ != stream_) (void)hipStreamSynchronize(own_);
   free_garbage();
   for (Ring &r : rings_) if (r.buf) (void)hipFree(r.buf);
@@ -1094,9 +1134,9 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
         a.tile = tile;
         a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
         a.tab_lds = tab_lds;
-        a.coop = sp.order >= 1 && sp.n % 8 == 0 && !getenv("RSMP_NO_POLYCOOP");
+        a.coop = sp.order >= 1 && sp.n % 8 == 0 && !knobs().no_polycoop;
         a.shared_rows = 0;
-        if (sp.order >= 1 && !getenv("RSMP_NO_POLYI")) { // the channels of a handle share the clock: share the interpolated rows
+        if (sp.order >= 1 && sp.n <= 32 && !knobs().no_polyi) { // (polyi_kernel maps 32 lanes along a coefficient row: n <= 32) // the channels of a handle share the clock: share the interpolated rows
           const double wl = 128 * in_per_out + sp.n + 4; // window of a 128-output tile (kPolyiTile)
           if ((128.0 * sp.n + 16.0 * (wl + 1)) * 8 <= 150.0 * 1024) { // rows + 16 channel windows must fit LDS
             a.shared_rows = 1;

@@ -30,10 +30,34 @@ struct Book {
                          // indexed absolutely, so the last fifo's positions lag them by this much after a drain
 };
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the object and puts the previous one back
+// afterwards.  Every C-ABI entry that takes a handle runs under one (capi.cpp): a handle lives on the device it was opened
+// on, whatever device the calling thread has selected since (the plugin is ONE process whose converter threads each own
+// handles, chain.h:36; with RATELIB_AMD_DEVICES / RRX_open_batch_on those handles may sit on different GPUs).
+class DeviceScope {
+public:
+  explicit DeviceScope(int device)
+  {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    if (device >= 0 && device != prev_) ok_ = hipSetDevice(device) == hipSuccess, switched_ = ok_;
+  }
+  ~DeviceScope() { if (switched_ && prev_ >= 0) (void)hipSetDevice(prev_); }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+  bool ok() const { return ok_; }
+private:
+  int prev_ = -1;
+  bool ok_ = true, switched_ = false;
+};
+
 class Engine {
 public:
-  static int create(const Config &cfg, int nch, int nstreams, Engine **out);
+  // device: HIP device index the handle lives on; -1 = the calling thread's current device.  kInvParam for an index the
+  // process does not have, kUninit for a device that is not gfx950.
+  static int create(const Config &cfg, int nch, int nstreams, int device, Engine **out);
   ~Engine();
+
+  int device() const { return device_; }
 
   const ChainPlan &plan() const { return plan_; }
   int nch() const { return nch_; }
@@ -101,6 +125,7 @@ private:
 
   ChainPlan plan_;
   int nch_ = 0, S_ = 0, C_ = 0;
+  int device_ = 0; // HIP device of every allocation, stream, event and launch of this handle (recorded by create)
   hipStream_t stream_ = nullptr; // where work is queued: own_ or the caller's (RRX_set_stream)
   hipStream_t own_ = nullptr;    // created by init, destroyed by the destructor; never the caller's
   hipEvent_t ev_switch_ = nullptr;
@@ -161,6 +186,6 @@ private:
   size_t slab_frames_ = 0;
 };
 
-bool device_is_gfx950(); // current HIP device runs gfx950 code objects
+bool device_is_gfx950(int device = -1); // the device (-1: the current one) runs gfx950 code objects
 
 } // namespace rsmp

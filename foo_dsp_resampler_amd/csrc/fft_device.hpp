@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "knobs.hpp" // RSMP_EXP_* (wrong-result timing experiments): 0 unless the build says -DRSMP_EXPERIMENTS
+
 namespace rsmp {
 
 struct c64 { double x, y; };
@@ -146,17 +148,9 @@ constexpr int fft_lds_doubles_halves(int log2m) { return fft_lds_doubles(log2m) 
 #ifndef RSMP_TWGEN_SQ
 #define RSMP_TWGEN_SQ 0
 #endif
-#ifndef RSMP_EXP_TWLOAD
-#define RSMP_EXP_TWLOAD 0
-#endif
-// timing experiment only (WRONG results): every twiddle load reads entry k = 0 of its row (one line per row: the loads stay,
-// their misses and most of their latency go) -- upper bound of what twiddle tables in LDS could buy
-#ifndef RSMP_EXP_TWK0
-#define RSMP_EXP_TWK0 0
-#endif
-#ifndef RSMP_EXP_NOBAR
-#define RSMP_EXP_NOBAR 0
-#endif
+// RSMP_EXP_TWK0 (timing experiment only, WRONG results; knobs.hpp): every twiddle load reads entry k = 0 of its row (one
+// line per row: the loads stay, their misses and most of their latency go) -- upper bound of what twiddle tables in LDS
+// could buy.  RSMP_EXP_TWLOAD: only the twiddles r = 1, 2, 4, 8 are loaded.
 template <bool BAR> __device__ __forceinline__ void rsmp_xbar()
 {
   if (BAR) (__syncthreads)();

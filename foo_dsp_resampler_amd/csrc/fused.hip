@@ -23,7 +23,8 @@
 #include <cstdlib>
 #include <cstdio>
 
-// Profiling switches (environment, read once per handle; all zero / unset in production):
+// Profiling switches (knobs.hpp; read once per process, all zero / unset in production).  The RSMP_DBG ablation bits give
+// WRONG results and only exist in -DRSMP_EXPERIMENTS builds (RSMP_DBGBITS is the constant 0 otherwise):
 //   RSMP_DBG bit 0 (1): skip the polyphase stage       bit 1 (2): skip the inverse FFT      bit 2 (4): skip the forward FFT
 //            bit 4 (16): compute the polyphase sums but do not store them
 //            bit 5 (32) / 6 (64): matrix-pipe variant, skip round B / round A
@@ -38,6 +39,11 @@
 // whole kernel does not (2.67 vs 2.63 ms): the polyphase phase loses the FFT phases it used to overlap with.
 #ifndef RSMP_FWD8
 #define RSMP_FWD8 0
+#endif
+#ifdef RSMP_EXPERIMENTS
+#define RSMP_DBGBITS (a.dbg)
+#else
+#define RSMP_DBGBITS 0
 #endif
 // twiddles per pass prefetched ahead of the preceding LDS exchange (forward / inverse transform of the MF variant)
 // RSMP_FINE=1 (variant builds only): per-segment cycle sums of the polyphase item loop of wave 0 in the stamped workgroups,
@@ -104,7 +110,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
   unsigned long long tstamp = stamping ? __builtin_readcyclecounter() : 0;
 #define RSMP_STAMP(slot) \
   if (stamping) { \
-    if (a.dbg & 256) __builtin_amdgcn_s_waitcnt(0); \
+    if (RSMP_DBGBITS & 256) __builtin_amdgcn_s_waitcnt(0); \
     const unsigned long long now = __builtin_readcyclecounter(); \
     if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp); \
     tstamp = now; \
@@ -189,13 +195,13 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       double2 g[16]; // in flight during the whole forward transform (32 + 64 registers live)
 #pragma unroll
       for (int s = 0; s < 16; ++s) g[s] = Gp[tid + s * T];
-      if (!(a.dbg & 4)) fft8_regs<LOG2P, -1>(u8, tid, a.d.tw_fwd8, lds);
+      if (!(RSMP_DBGBITS & 4)) fft8_regs<LOG2P, -1>(u8, tid, a.d.tw_fwd8, lds);
       RSMP_STAMP(1)
 #pragma unroll
       for (int s = 0; s < 16; ++s) v[s] = cmul(u8[s & 7], c64{g[s].x, g[s].y});
       __syncthreads(); // the inverse transform's exchange reuses the LDS the forward one just read
     } else {
-    if (!(a.dbg & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0, MF ? RSMP_PFW : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
+    if (!(RSMP_DBGBITS & 4)) fft_regs<LOG2P, -1, (MF && LOG2P == LOG2N) ? 2 : 0, MF ? RSMP_PFW : 0>(v, tid, fwd_active, a.d.tw_fwd, lds);
     RSMP_STAMP(1)
     }
     if constexpr (FWD8) {
@@ -251,7 +257,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       }
     }
     RSMP_STAMP(2)
-    if (!(a.dbg & 2)) fft_regs<LOG2N, +1, MF ? 2 : 0, MF ? RSMP_PFI : 0>(v, tid, true, a.d.tw_inv, lds);
+    if (!(RSMP_DBGBITS & 2)) fft_regs<LOG2N, +1, MF ? 2 : 0, MF ? RSMP_PFI : 0>(v, tid, true, a.d.tw_inv, lds);
     RSMP_STAMP(3)
 
     // coefficient tile of this thread: rows of its G phases shifted to a common window start and zero
@@ -314,7 +320,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       const int hi = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
       const int irel_hi = fb.irel_lo + fb.cnt;
-      const bool run = !(a.dbg & 1) && fb.cnt > 0;
+      const bool run = !(RSMP_DBGBITS & 1) && fb.cnt > 0;
 
       bool ofast = false;
       float *obase = nullptr; // frame i_lo's first float of this pair
@@ -424,7 +430,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
             for (int s = 0; s < SPAN; ++s) ca_[s] = cn_[s];
             flush();
             RSMP_TICK(10, 0)  // conversions + store issue
-            if (!(a.dbg & 1024)) {
+            if (!(RSMP_DBGBITS & 1024)) {
               const int nx = it + NW < 2 * a.NGRP ? it + NW : wave; // wraps to the first item of the next round
               const double *cp = a.cfm + (nx >> 1) * (SPAN * 64);    // uniform base, lane offset added by the load
 #pragma unroll
@@ -463,14 +469,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
 #pragma unroll
             for (int u = 0; u < MAXCS; ++u) {
               if (cs0 + u < cs1) {
-                if (cs0 + u + 1 < cs1 && !(a.dbg & 512)) fill((u & 1) ? x0 : x1, cs0 + u + 1);
+                if (cs0 + u + 1 < cs1 && !(RSMP_DBGBITS & 512)) fill((u & 1) ? x0 : x1, cs0 + u + 1);
                 column_step((u & 1) ? x1 : x0, pA[u], pB[u]);
               }
             }
             RSMP_TICK(13, 0)  // column steps
             // bookkeeping for the deferred stores
             const int rD = 16 * g + 4 * bq + hi, k0 = kb + 4 * cs0;
-            pend_n = (a.dbg & 16) ? 0 : cs1 - cs0;
+            pend_n = (RSMP_DBGBITS & 16) ? 0 : cs1 - cs0;
             pend_ib = (k0 + jq) * pl + rD;
             pend_off = (pend_ib - fb.irel_lo) * frame_bytes;
             pend_hi = rD < pl ? min(irel_hi, ke * pl) : -1;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
           }
         };
         // round A: periods whose windows end inside the samples written above
-        if (run && !(a.dbg & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
+        if (run && !(RSMP_DBGBITS & 64)) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * SPAN);
         RSMP_STAMP(6)
         __syncthreads();
         // round B: the rest of the block's samples replace the image, element 0 = sample kSB0*T
@@ -499,7 +505,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
           if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
         }
         __syncthreads();
-        if (run && fb.KA < fb.K && !(a.dbg & 32))
+        if (run && fb.KA < fb.K && !(RSMP_DBGBITS & 32))
           poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * SPAN);
         flush();
       };
@@ -507,7 +513,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
       else both_rounds(std::false_type{});
     } else
     // ---------------------------------------------------------------- polyphase FIR from LDS (vector pipe)
-    if (!(a.dbg & 1) && poly_thread && fb.cnt > 0) {
+    if (!(RSMP_DBGBITS & 1) && poly_thread && fb.cnt > 0) {
       const int irel_hi = fb.irel_lo + fb.cnt;
       const int kper = a.kper; // fixed chunk length (not per block) so that the lane map's bank pattern is static
       const int kr0 = kc * kper, kr1 = min(kr0 + kper, fb.K);
@@ -556,7 +562,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, MF ? kFusedWaves : 2) void fused
             accB[g] = fma(cf[g][mm], xv.y, accB[g]);
           }
         }
-        if (a.dbg & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
+        if (RSMP_DBGBITS & 16) { if (accA[0] == 12345.678) lds[0] = accB[0] + accA[1] + accB[1]; continue; }
         const int orel = ib - fb.irel_lo; // frame offset from i_lo (-1 for a tile whose first output is a seam output)
         if (ofast) {
           float2 *o2 = reinterpret_cast<float2 *>(obase) + orel * ostride;
@@ -683,7 +689,7 @@ template <int LOG2N, int LOG2P, int G, int SPAN, bool MF>
 static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const FusedArgs &a, hipStream_t st)
 {
   constexpr int N = 1 << LOG2N;
-  static const size_t lds_pad = getenv("RSMP_LDS_PAD") ? size_t(atoi(getenv("RSMP_LDS_PAD"))) : 0; // occupancy experiments
+  const size_t lds_pad = knobs().lds_pad; // occupancy experiments
   size_t lds_bytes = 8 * size_t(fft_lds_doubles(LOG2N));
   if (MF) { // half-round exchanges for 4096-point transforms, two-round sample image (fused_kernel, MF part)
     lds_bytes = 8 * size_t(fft_lds_doubles_halves(LOG2N));
@@ -691,13 +697,11 @@ static hipError_t launch_fused_t(const AnyView &in, const AnyView &out, const Fu
     lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
   }
   lds_bytes += lds_pad;
-  static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
-  if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_done.store(true, std::memory_order_release);
-    if (getenv("RSMP_OCC")) {
+  static DynLdsOnce attr;
+  static std::atomic<bool> occ_printed{false};
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), int(lds_bytes)); e != hipSuccess) return e;
+  {
+    if (knobs().occ && !occ_printed.exchange(true)) {
       int nb = -1;
       hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&fused_kernel<LOG2N, LOG2P, G, SPAN, MF>), N / 16, lds_bytes);
       fprintf(stderr, "RSMP_OCC lds %zu blocks/CU %d (%s)\n", lds_bytes, nb, hipGetErrorString(eo));

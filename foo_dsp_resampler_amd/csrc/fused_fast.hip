@@ -32,21 +32,13 @@
 #ifndef RSMP_TWGEN
 #define RSMP_TWGEN 1
 #endif
-#ifndef RSMP_EXP_HALFMFMA
-#define RSMP_EXP_HALFMFMA 0
-#endif
 // output stores as raw buffer stores with the range check done by the buffer descriptor (no per-tile compare / branch)
 #ifndef RSMP_BUFSTORE
 #define RSMP_BUFSTORE 1
 #endif
-// timing experiments only (WRONG results): bit 0 = every coefficient tile is group 0's, bit 1 = every G value is slot 0's
-// (the loads stay, their L1 misses go: upper bounds of what smaller / shared tables could buy)
-#ifndef RSMP_EXP_TAB
-#define RSMP_EXP_TAB 0
-#endif
-#ifndef RSMP_EXP_LINEAR
-#define RSMP_EXP_LINEAR 0
-#endif
+// RSMP_EXP_TAB / RSMP_EXP_LINEAR / RSMP_EXP_HALFMFMA (knobs.hpp; -DRSMP_EXPERIMENTS builds only, WRONG results): bit 0 = every
+// coefficient tile is group 0's, bit 1 = every G value is slot 0's (the loads stay, their L1 misses go: upper bounds of what
+// smaller / shared tables could buy); lane-linear window reads; 6 of every 14 MFMAs removed
 #ifndef RSMP_PRIO
 #define RSMP_PRIO 0
 #endif
@@ -393,13 +385,8 @@ template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const F
   size_t lds_bytes = 8 * size_t(fft_lds_doubles_halves(12));
   if (LOG2P < 12) lds_bytes = std::max(lds_bytes, 8 * size_t(std::max(fft_lds_doubles(LOG2P), fft8_lds_doubles(LOG2P))));
   lds_bytes = std::max(lds_bytes, size_t(kPad + kSA * (N / 16) + kPad) * 16);
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_fast_kernel<LOG2P, KS, OUT64>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_done.store(true, std::memory_order_release);
-  }
+  static DynLdsOnce attr;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_fast_kernel<LOG2P, KS, OUT64>), int(lds_bytes)); e != hipSuccess) return e;
   FusedArgs b = a;
   b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
   dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(N / 16);
@@ -409,8 +396,7 @@ template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const F
 
 bool fused_fast_supported(int log2n, int log2p, int ksteps)
 {
-  static const bool off = getenv("RSMP_NO_FAST") != nullptr;
-  return !off && log2n == 12 && (log2p == 11 || log2p == 12) && (ksteps == 7 || ksteps == 8);
+  return !knobs().no_fast && log2n == 12 && (log2p == 11 || log2p == 12) && (ksteps == 7 || ksteps == 8);
 }
 
 #define RSMP_FAST_CASE(p, ks)                                                                        \

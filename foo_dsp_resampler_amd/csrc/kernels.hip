@@ -696,13 +696,8 @@ static hipError_t launch_dft_t(const AnyView &in, const AnyView &out, const DftA
                                : (LOG2N == 13 && LOG2ND == 13)
                                    ? std::max(8 * size_t(fft_lds_doubles_halves(13)), LOG2P < LOG2N ? 8 * size_t(fft_lds_doubles(LOG2P)) : 0)
                                    : 8 * size_t(fft_lds_doubles(LOG2N)));
-  static std::atomic<bool> attr_done{false}; // idempotent, so a race between two handles' threads is harmless
-  if (!attr_done.load(std::memory_order_acquire)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND, SP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_done.store(true, std::memory_order_release);
-  }
+  static DynLdsOnce attr;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&dft_kernel<LOG2N, LOG2P, LOG2ND, SP>), int(lds_bytes)); e != hipSuccess) return e;
   DftArgs b = a;
   b.hp = frame_pairs(in, out, a.C);
   b.npairs = pair_count(a.C, a.nchs);
@@ -762,13 +757,8 @@ hipError_t launch_poly(int order, bool src_f32, bool dst_f32, const F32View &sf,
     dim3 pgrid((unsigned)ptiles, (unsigned)gy);
     const size_t pl = sizeof(double) * (size_t(kPolyiTile) * a.n + size_t(kPolyiCh) * a.win);
     // (idempotent; the size only grows with the stage's window, so raising the limit to 150 KB once per instance is enough)
-    static std::atomic<int> attr_done{0};
-    auto set_attr = [&](const void *fn) {
-      if (attr_done.load(std::memory_order_acquire) & (1 << order)) return hipSuccess;
-      hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      if (ea == hipSuccess) attr_done.fetch_or(1 << order, std::memory_order_release);
-      return ea;
-    };
+    static DynLdsOnce attr[4];
+    auto set_attr = [&](const void *fn) { return attr[order].set(fn, 150 * 1024); };
     hipError_t e = hipSuccess;
     switch (order) {
       case 1: e = set_attr(reinterpret_cast<const void *>(&polyi_kernel<1>)); if (e == hipSuccess) hipLaunchKernelGGL(polyi_kernel<1>, pgrid, block, pl, st, in, out, a); break;

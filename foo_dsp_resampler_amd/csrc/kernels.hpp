@@ -6,9 +6,29 @@
 // why one set of indices serves every channel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
+#include "knobs.hpp"
+
 namespace rsmp {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one process may hold handles on several
+// GPUs (RRX_open_batch_on), so "already set" is remembered per (kernel instance, device).  Setting it twice is harmless,
+// so a race between two handles' threads needs no lock.
+struct DynLdsOnce {
+  std::atomic<unsigned long long> mask{0};
+  hipError_t set(const void *fn, int bytes)
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+  }
+};
 
 // Interleaved float32 frames: the caller-facing end of the chain (stage-0 input or final output).
 // A frame with absolute index a lives in the external buffer when ext != nullptr and

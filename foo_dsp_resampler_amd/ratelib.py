@@ -12,7 +12,7 @@ RR_BEST, RR_NORM = 0, 1
 # every symbol the two public headers declare
 EXPECTED_SYMBOLS = [
     "init_ratelib", "close_ratelib", "RR_open", "RR_flow", "RR_push", "RR_pull", "RR_drain", "RR_close", "RR_strerror",
-    "RRX_open_batch", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
+    "RRX_open_batch", "RRX_open_batch_on", "RRX_device", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
     "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_profile_report", "RRX_debug_fail_alloc", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
     "RRX_describe_plan", "RRX_plan_table",
 ]
@@ -89,6 +89,8 @@ def lib():
         L.init_ratelib.argtypes = [_ALLOC_CB]
         L.RR_open.argtypes = [P(RRConfig), C.c_int, P(vp)]
         L.RRX_open_batch.argtypes = [P(RRConfig), C.c_int, C.c_int, P(vp)]
+        L.RRX_open_batch_on.argtypes = [P(RRConfig), C.c_int, C.c_int, C.c_int, P(vp)]
+        L.RRX_device.argtypes = [vp]
         L.RR_push.argtypes = [vp, vp, sz]
         L.RR_pull.argtypes = [vp, vp, sz, P(sz)]
         L.RR_flow.argtypes = [vp, vp, vp, sz, sz, P(sz), P(sz)]
@@ -172,13 +174,15 @@ class Resampler:
     Device buffers are anything with `data_ptr()` (torch CUDA tensors) of the same shapes.
     """
 
-    def __init__(self, in_rate, out_rate, nch=2, nstreams=1, **kw):
+    def __init__(self, in_rate, out_rate, nch=2, nstreams=1, device=None, **kw):
         _ensure_init()
         self.L = lib()
         self.nch, self.nstreams = nch, nstreams
         self.cfg = _config(in_rate, out_rate, **kw)
         self.h = C.c_void_p()
-        if nstreams == 1:
+        if device is not None:  # explicit HIP device index (RRX_open_batch_on)
+            _check(self.L.RRX_open_batch_on(C.byref(self.cfg), nch, nstreams, int(device), C.byref(self.h)), "RRX_open_batch_on")
+        elif nstreams == 1:
             _check(self.L.RR_open(C.byref(self.cfg), nch, C.byref(self.h)), "RR_open")
         else:
             _check(self.L.RRX_open_batch(C.byref(self.cfg), nch, nstreams, C.byref(self.h)), "RRX_open_batch")
@@ -193,6 +197,10 @@ class Resampler:
             self.close()
         except Exception:
             pass
+
+    @property
+    def device(self):
+        return self.L.RRX_device(self.h)
 
     @property
     def isamp_max(self):

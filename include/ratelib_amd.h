@@ -23,6 +23,19 @@ extern "C" {
  * channel of each stream rides alone, exactly as in a one-stream handle). */
 int RRX_open_batch(const RR_config *config, int nchannels, int nstreams, RR_handle **const handle);
 
+/* Devices.  A handle lives on ONE HIP device: all of its memory, streams and launches.  Every entry point of both headers
+ * selects that device for the duration of the call and restores the caller's afterwards, so a handle may be used from any
+ * thread whatever device that thread has current (one thread at a time per handle, as in the reference: SURVEY 8b).
+ *   RR_open / RRX_open_batch place the handle on the calling thread's current device, or -- when the environment variable
+ *   RATELIB_AMD_DEVICES ("all", or a comma list of device indices) was set at init_ratelib -- deal new handles round-robin
+ *   over those devices: the unchanged plugin, one process with one handle per converter thread (chain.h:36), then spreads
+ *   over the GPUs of a node by itself (channels / streams are independent, rate/rate_base.h:533-540: no collective).
+ *   RRX_open_batch_on names the device explicitly: RR_INVPARAM for an index the process does not have (or < 0),
+ *   RR_EXTUNINIT for a device that is not gfx950.
+ * Device pointers handed to RRX_*_device must be accessible from the handle's device; RRX_device reports it (-1: NULL). */
+int RRX_open_batch_on(const RR_config *config, int nchannels, int nstreams, int device, RR_handle **const handle);
+int RRX_device(const RR_handle *h);
+
 /* Device-pointer forms of RR_push / RR_pull / RR_flow (rate/ratelib.h:75-77).  Pointers are HBM
  * addresses valid on the handle's HIP stream; calls only enqueue work (no host synchronisation),
  * the frame counts they return are exact because availability never depends on sample values.
@@ -39,8 +52,9 @@ int RRX_pull_strided(RR_handle *h, fb_sample_t *obuf, size_t out_stride, size_t 
 /* Use the caller's hipStream_t (passed as void*) for all work of this handle from now on.  NULL is the device's default
  * stream, as in every HIP call (it is also what PyTorch's default stream is); RRX_STREAM_OWN restores the stream the
  * handle created for itself at RR_open, which is what a handle uses until this is called.  The caller keeps ownership of
- * its stream (RR_close never destroys it); work already queued on the previous stream is ordered before the work queued
- * after the switch.  RRX_sync blocks until everything enqueued so far has finished. */
+ * its stream: RR_close never destroys it, but waits on it, so a caller-owned stream must outlive RR_close.  Work already
+ * queued on the previous stream is ordered before the work queued after the switch.  RRX_sync blocks until everything
+ * enqueued so far has finished. */
 #define RRX_STREAM_OWN ((void *)(~(size_t)0))
 int RRX_set_stream(RR_handle *h, void *hip_stream);
 int RRX_sync(RR_handle *h);
@@ -57,7 +71,8 @@ int RRX_profile_read(RR_handle *h, double *hot_ms, long long *hot_launches, doub
  * to cap-1 bytes) or the negated RR_error. */
 int RRX_profile_report(RR_handle *h, char *buf, size_t cap);
 
-/* Test hook (fault injection): the nth device allocation from now on, counted process-wide, fails as if the GPU were
+/* Test hook (fault injection), inert unless the process was started with RSMP_TEST_HOOKS set in its environment (read once,
+ * at init_ratelib): the nth device allocation from now on, counted process-wide, fails as if the GPU were
  * out of memory (RR_ENOMEM + the init_ratelib handler, rate/xmalloc.c:38-43); 0 disarms.  A failure in the middle of a
  * push or drain poisons the handle: every later data call returns RR_INTERNAL until it is closed (its counters no
  * longer describe the device fifos; the reference has no recovery path either, chain.h:26-29 tears the chain down). */

@@ -1,0 +1,216 @@
+"""Round-3 GPU tests: device-aware handles, the self-launching multi-rank bench, the bench shapes of BASELINE configs[2] and
+configs[3] against the oracle, RR_flow against the oracle's orc_flow, allocation failures inside RR_open.
+Everything goes through the C ABI of libratelib_amd.so (ctypes mirror in foo_dsp_resampler_amd/ratelib.py)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import foo_dsp_resampler_amd as F
+from foo_dsp_resampler_amd import ratelib as R
+from oracle_binding import Oracle, lcg_noise
+from parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------ devices (VERDICT r2 #1b)
+def test_handle_remembers_its_device_and_works_from_another_thread():
+    """A handle opened on device 0 by one thread is driven by another thread (the plugin's converter threads, chain.h:36):
+    every ABI entry selects the handle's device itself.  Output equals the oracle's."""
+    x = lcg_noise(30000, 2, 5)
+    r = F.Resampler(44100, 96000, nch=2, device=0)
+    assert r.device == 0
+    out = {}
+
+    def work():
+        try:
+            out["y"] = r.process(x, chunk=7000)
+        except Exception as e:  # surfaced below
+            out["err"] = e
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "err" not in out, out.get("err")
+    assert_parity(out["y"], Oracle(44100, 96000, 2).process(x, chunk=7000))
+    # the default placement is the calling thread's current device
+    assert F.Resampler(44100, 48000, nch=1).device == 0
+
+
+def test_open_on_a_device_the_process_does_not_have_fails_cleanly():
+    torch = pytest.importorskip("torch")
+    L = F.lib()
+    R._ensure_init()
+    n = torch.cuda.device_count()
+    cfg = F.RRConfig(44100, 96000, 50.0, 95.0, 0, 0)
+    for dev in (n, n + 5, -1, -7):
+        h = C.c_void_p(0x1234)
+        rc = L.RRX_open_batch_on(C.byref(cfg), 2, 4, dev, C.byref(h))
+        assert rc == 6 and not h.value, (dev, rc, h.value)  # RR_INVPARAM, *handle NULL
+    assert L.RRX_device(None) == -1
+    # ... and the library still works afterwards
+    x = lcg_noise(5000, 2, 1)
+    assert_parity(F.Resampler(44100, 48000, 2).process(x), Oracle(44100, 48000, 2).process(x))
+    if n > 1:  # a second GPU, when the box has one: the same handle API on device 1
+        r = F.Resampler(44100, 96000, nch=2, nstreams=3, device=1)
+        assert r.device == 1
+        xs = np.stack([lcg_noise(20000, 2, 40 + k) for k in range(3)])
+        ys = r.process(xs)
+        for k in range(3):
+            assert_parity(ys[k], Oracle(44100, 96000, 2).process(xs[k]))
+
+
+def test_device_round_robin_from_the_environment():
+    """RATELIB_AMD_DEVICES=all (read at init_ratelib): RR_open deals handles over the devices.  Own process, because the
+    variable is read once."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import foo_dsp_resampler_amd as F, torch\n"
+        "from oracle_binding import Oracle, lcg_noise\n"
+        "from parity import assert_parity\n"
+        "n = torch.cuda.device_count()\n"
+        "hs = [F.Resampler(44100, 48000, nch=2) for _ in range(2 * n + 1)]\n"
+        "assert [h.device for h in hs] == [k %% n for k in range(2 * n + 1)], [h.device for h in hs]\n"
+        "x = lcg_noise(9000, 2, 3)\n"
+        "ref = Oracle(44100, 48000, 2).process(x)\n"
+        "for h in hs: assert_parity(h.process(x), ref)\n"
+        "print('ok', n)\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, RATELIB_AMD_DEVICES="all")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), p.stderr[-2000:]
+    bad = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nimport foo_dsp_resampler_amd as F\nF.Resampler(44100, 48000)" % ROOT],
+                         env=dict(os.environ, RATELIB_AMD_DEVICES="0,99"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "init_ratelib failed" in bad.stderr  # names a device the process does not have
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank launch (VERDICT r2 #1a)
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: two fresh child processes (one rank each, both on this box's one GPU,
+    gloo for the barrier / MAX), one JSON line from rank 0 with n_gpus 2, whole-job units = both ranks', stream 0 of the
+    last timed step checked against the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(BENCH_SHARE_GPU="1", BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "16",
+                        "--frames", "100000", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["checked"] is True, out
+    per_rank_units = 16 * 100000 * 2
+    assert abs(out["value"] * 1e6 * out["ms_per_step"] / 1e3 - 2 * per_rank_units) < 1e-3 * per_rank_units  # whole-job aggregate
+
+
+# ------------------------------------------------------------------------------------------------ bench shapes
+def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
+    """bench.py's workload for one BASELINE config: S streams x isamp_max frames per push, device-resident in and out
+    through RRX_flow_device, two steps (the second one starts from the first one's fifo state, slab cuts included), then a
+    drain.  `check_streams` sample by sample against the oracle, every stream by frame count and a distinct checksum."""
+    torch = pytest.importorskip("torch")
+    import bench
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    n = r.isamp_max
+    x = bench.lcg_noise_device(torch, S, n, nch, 12345, "cuda")
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    cap = int(n * fo / fi) + 8192
+    ys, ogs = [], []
+    for _ in range(2):
+        y = torch.zeros((S, cap, nch), device="cuda")
+        iu, og = r.flow_device(x, n, y, cap)
+        assert iu == n
+        ys.append(y)
+        ogs.append(og)
+    r.drain()
+    tail = torch.zeros((S, 16384, nch), device="cuda")
+    og2 = r.pull_device(tail, 16384)
+    r.sync()
+    assert sum(ogs) + og2 == int(2 * n * fo / fi + .5)
+    for s in check_streams:
+        xs = x[s].cpu().numpy()
+        assert np.array_equal(xs, lcg_noise(n, nch, 12345 + s).reshape(n, nch))  # the generator bench.py uses IS SURVEY 8(d)'s LCG
+        o = Oracle(fi, fo, nch, **kw)
+        for k in range(2):
+            o.push(xs)
+            ref = o.pull_all(1 << 20)
+            assert ref.shape[0] == ogs[k], (k, ref.shape, ogs[k])  # same frames pullable after every push
+            assert_parity(ys[k][s, :ogs[k]].cpu().numpy(), ref)
+        o.drain()
+        assert_parity(tail[s, :og2].cpu().numpy(), o.pull_all())
+    for k in range(2):
+        sums = ys[k][:, :ogs[k]].double().abs().sum(dim=(1, 2)).cpu().numpy()
+        assert np.all(np.isfinite(sums)) and len(np.unique(sums)) == S
+
+
+def test_cfg2_bench_shape_against_oracle():
+    """BASELINE configs[2]: 44.1k->192k, 8 ch, passband 99 % (16384-point dft -> vpoly0 -> x4 dft), 32 streams x 240 844 frames."""
+    _bench_shape_case(44100, 192000, 8, 32, {"bandwidth": 99.0}, (0, 17, 31))
+
+
+def test_cfg3_bench_shape_against_oracle():
+    """BASELINE configs[3]: 96k->44.1k, 32 ch, aliasing off, linear phase, 16 streams x 1 048 576 frames (item_map with 16
+    pairs per frame)."""
+    _bench_shape_case(96000, 44100, 32, 16, {"allow_aliasing": 0, "phase": 50.0}, (0, 9, 15))
+
+
+def test_cfg0_bench_shape_against_oracle():
+    """BASELINE configs[0] as bench.py --config 0 runs it: 44.1k->48k stereo, 256 streams x 963 379 frames."""
+    _bench_shape_case(44100, 48000, 2, 256, {}, (0, 100, 255))
+
+
+# ------------------------------------------------------------------------------------------------ RR_flow vs orc_flow
+@pytest.mark.parametrize("fi,fo,nch", [(44100, 96000, 2), (96000, 44100, 3), (44100, 48001, 1)])
+def test_flow_against_the_oracles_flow(fi, fo, nch):
+    """RR_flow (rate_base.h:571-614) call by call against the oracle's restatement of the same function: small osamp, so
+    output piles up in the last fifo between calls; input-less calls; osamp 0; identical iused / ogen and samples."""
+    x = lcg_noise(60000, nch, 11).reshape(-1, nch)
+    r, o = F.Resampler(fi, fo, nch), Oracle(fi, fo, nch)
+    pos = 0
+    plan = [(5000, 100), (3000, 0), (0, 4000), (12000, 50000), (1, 7), (0, 0), (20000, 900), (0, 100000), (7000, 3), (12999, 100000)]
+    for isamp, osamp in plan:
+        seg = x[pos:pos + isamp]
+        iu_g, y_g = r.flow(seg, osamp)
+        iu_o, y_o = o.flow(seg, osamp)
+        assert iu_g == iu_o == isamp, (isamp, osamp, iu_g, iu_o)
+        assert y_g.shape == y_o.shape, (isamp, osamp, y_g.shape, y_o.shape)
+        if y_o.size:
+            assert_parity(y_g, y_o)
+        pos += isamp
+    r.drain(); o.drain()
+    a, b = r.pull_all(), o.pull_all()
+    assert a.shape == b.shape
+    assert_parity(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ allocation failures inside RR_open
+def test_allocation_failure_in_the_middle_of_open():
+    """RRX_debug_fail_alloc(k) armed BEFORE RR_open: the k-th device allocation of the handle's construction fails.
+    RR_ENOMEM, *handle NULL, the init_ratelib handler runs exactly once (xmalloc.c:38-43), the half-built engine is torn
+    down, and the next open / process still matches the oracle."""
+    L = F.lib()
+    R._ensure_init()
+    x = lcg_noise(12000, 2, 9)
+    ref = Oracle(44100, 96000, 2).process(x)
+    cfg = F.RRConfig(44100, 96000, 50.0, 95.0, 0, 0)
+    hit = 0
+    for k in (1, 2, 3, 5, 8, 12, 40):
+        before = R.alloc_handler_calls
+        L.RRX_debug_fail_alloc(k)
+        h = C.c_void_p(0x1234)
+        rc = L.RR_open(C.byref(cfg), 2, C.byref(h))
+        L.RRX_debug_fail_alloc(0)
+        if rc == 0:  # the construction makes fewer than k allocations: nothing failed
+            L.RR_close(C.byref(h))
+            assert R.alloc_handler_calls == before
+            continue
+        hit += 1
+        assert rc == 1 and not h.value, (k, rc, h.value)  # RR_ENOMEM, NULL handle
+        assert R.alloc_handler_calls == before + 1, k
+        assert_parity(F.Resampler(44100, 96000, 2).process(x), ref)
+    assert hit >= 5
