@@ -315,7 +315,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     fu.blk_cap = 64;
     while (fu.blk_cap < kFusedMaxBlocks && size_t(C_ + 1) * size_t(4 * fu.blk_cap) * 512 <= (size_t(320) << 20)) fu.blk_cap *= 2;
     fu.slots = 2 * fu.blk_cap;
-    ALLOC_TRY(&fu.blk_dev, size_t(fu.blk_cap) * sizeof(FusedBlock));
+    ALLOC_TRY(&fu.blk_dev, size_t(2 * fu.blk_cap) * sizeof(FusedBlock)); // two halves: launch k uses half k & 1 (see advance)
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
     ALLOC_TRY(&fu.seam, bytes);
     HIP_TRY(hipMemset(fu.seam, 0, bytes));
@@ -785,7 +785,7 @@ void Engine::note_input(Book &b, size_t n) const
 
 // One pass of rate_process (rate_base.h:425-432) after `n_new` frames were appended to fifo 0.
 // With launch == false only the counters move (used to size a drain).
-int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout)
+int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout, bool more_slabs)
 {
   const int ns = int(plan_.stages.size());
   note_input(b, n_new);
@@ -966,14 +966,23 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           pa.clip_hi = 0x7fffffffffffffffLL;
           for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
             if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
-          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, fu.blk_dev, stream_)); prof_end(pp); }
-          fa.blk = fu.blk_dev;
+          // side stream for the seam kernel only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
+          // ... and only when another slab of this push follows: seam(k) then runs beside fused(k+1).  Behind the LAST fused
+          // launch of a push the side stream has nothing to overlap with but the small carry copy, and the two cross-queue
+          // hand-overs (event -> side stream -> join) cost more than they hide: 2.455 against 2.505 ms per step measured.
+          const bool seam_on_side = more_slabs && !(profiling_ || !dst_f32 || no_side_);
+          // seam(k-2), possibly still pending on the side stream, reads the seam-ring slots AND the half of the block table
+          // that this launch is about to overwrite: both the table fill and the fused launch wait for it.  (The table has
+          // two halves, launch k uses half k & 1: seam(k-1) may still be reading the other one.  With ONE table, a push cut
+          // into three launches lost the seam outputs of its first blocks: tests/test_gpu_round3.py::test_cfg0_bench_shape_*.)
+          if (seam_launches_ >= 2) HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
+          FusedBlock *const blk_half = fu.blk_dev + size_t(seam_launches_ & 1) * fu.blk_cap;
+          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, blk_half, stream_)); prof_end(pp); }
+          fa.blk = blk_half;
           // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
           const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
           if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
           const bool s32 = i - 1 == 0;
-          if (seam_launches_ >= 2) // seam(k-2) read the slots this launch overwrites
-            HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
           // Blocks whose input span and outputs lie in the caller's buffers as plain interleaved frames go to the lean
           // kernel (fused_fast.hip); the others (the block that straddles ring and buffer, ring wrap, odd channel counts,
           // fp64 rings on either side) to the generic one.  At most three launches: generic head, lean middle, generic tail.
@@ -1044,8 +1053,8 @@ int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const 
           { int rl = launch_range(0, f0, false); if (rl) return rl; }
           { int rl = launch_range(f0, f1, true); if (rl) return rl; }
           { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
-          // side stream only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
-          if (profiling_ || !dst_f32 || no_side_) {
+          if (!seam_on_side) {
+            { int rcj = join_side(); if (rcj) return rcj; } // (a seam kernel of an earlier launch of this push may still be on the side stream)
             const int ps = prof_begin(false, "rsmp::seam_kernel");
             HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
             prof_end(ps);
@@ -1219,7 +1228,7 @@ int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, flo
   size_t done = 0;
   while (done < isamp) {
     const size_t n = std::min(slab_frames_, isamp - done);
-    int rc = advance(book_, n, true, ein, eout);
+    int rc = advance(book_, n, true, ein, eout, done + n < isamp);
     if (rc) return rc;
     done += n;
   }

@@ -112,7 +112,8 @@ private:
            size_t *direct_out);
   int feed_impl(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
                 size_t *direct_out);
-  int advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout);
+  // more_slabs: another time slab of the same push follows (seam kernels may then run beside the next slab's launches)
+  int advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout, bool more_slabs = false);
   int ensure_ring(int f, long long live_needed);
   int copy_out(float *dst, size_t stride_frames, size_t frames, bool to_host);
   F32View f32_view(int f, const ExtIn *ein, const ExtOut *eout) const;

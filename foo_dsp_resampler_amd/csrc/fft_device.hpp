@@ -416,6 +416,97 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
   }
 }
 
+// ---- the same transform with its twiddles PRELOADED: every table read of a thread (w^1, w^2 (, w^4) of each twiddled pass, the
+// rest multiplied up as in the TWGEN form) is issued by fft8_tw_load in one go, typically next to the block's input loads, so
+// the whole transform pays one memory round trip instead of one per pass (hipcc does not hoist a pass's table loads over the
+// s_barrier of the exchange in front of it: in fft8_regs each pass exposes a full L2 latency).  Same arithmetic, same bits.
+constexpr int fft8_tw_regs(int log2m)
+{ // double2 registers per thread: passes 1 .. NP-2 are radix 8 (3 loads), the last one radix RL on 8 / RL butterflies
+  const int np = fft8_num_passes(log2m), rl = fft8_last_radix(log2m);
+  return 3 * (np - 2) + (8 / rl) * (rl == 8 ? 3 : rl == 4 ? 2 : 1);
+}
+template <int LOG2M> __device__ __forceinline__ void fft8_tw_load(double2 (&w)[fft8_tw_regs(LOG2M)], int tid, const double2 *__restrict__ tw)
+{
+  constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M), T8 = (1 << LOG2M) / 8;
+  int o = 0, ns = 8;
+  const double2 *t = tw;
+#pragma unroll
+  for (int p = 1; p < NP; ++p) {
+    const int R = p + 1 == NP ? RL : 8, NB = 8 / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int k = (tid + b * T8) & (ns - 1);
+#pragma unroll
+      for (int r = 1; r < R; r <<= 1) w[o++] = t[(r - 1) * ns + k];
+    }
+    t += (R - 1) * ns;
+    ns *= 8;
+  }
+}
+// one twiddled pass on preloaded twiddles `w` (this pass's registers start at w[O])
+template <int LOG2M, int R, int NS, int DIR, bool LAST, int O, int NW>
+__device__ __forceinline__ void fft8_pass_pre(c64 (&u)[8], int tid, const double2 (&wr)[NW], double *lds)
+{
+  constexpr int T8 = (1 << LOG2M) / 8, NB = 8 / R, PER = R == 8 ? 3 : R == 4 ? 2 : 1;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    c64 b[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) b[r] = u[t + NB * r];
+    c64 w[8];
+#pragma unroll
+    for (int r = 1, i = 0; r < R; r <<= 1, ++i) w[r] = {wr[O + t * PER + i].x, wr[O + t * PER + i].y};
+    if (R >= 4) w[3] = cmul(w[1], w[2]);
+    if (R == 8) {
+      w[5] = cmul(w[4], w[1]);
+      w[6] = cmul(w[4], w[2]);
+      w[7] = cmul(w[4], w[3]);
+    }
+#pragma unroll
+    for (int r = 1; r < R; ++r) b[r] = DIR > 0 ? cmul(b[r], w[r]) : cmulc(b[r], w[r]);
+    Bfly<R, DIR>::run(b);
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[t + NB * r] = b[r];
+  }
+  if (!LAST) {
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int j = tid + t * T8, k = j & (NS - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) l2[(j - k) * R + k + r * NS] = make_double2(u[t + NB * r].x, u[t + NB * r].y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const double2 q = l2[tid + s * T8];
+      u[s] = {q.x, q.y};
+    }
+    __syncthreads();
+  }
+}
+// all threads of the workgroup hold points (M / 8 threads); `between(p)` runs after pass p and its exchange (p = 0 .. NP-2):
+// the caller's hook for issuing further loads into registers that only just became free
+template <int LOG2M, int DIR, typename Hook>
+__device__ __forceinline__ void fft8_regs_pre(c64 (&u)[8], int tid, const double2 (&w)[fft8_tw_regs(LOG2M)], double *lds, Hook between)
+{
+  constexpr int NP = fft8_num_passes(LOG2M), RL = fft8_last_radix(LOG2M), NW = fft8_tw_regs(LOG2M);
+  static_assert(NP >= 3 && NP <= 4, "fft8_regs_pre: 512 <= M <= 4096");
+  fft8_pass<LOG2M, 8, 1, DIR, false, true>(u, tid, nullptr, lds, true); // twiddle-free first pass (padded exchange)
+  between(0);
+  if constexpr (NP == 3) {
+    fft8_pass_pre<LOG2M, 8, 8, DIR, false, 0, NW>(u, tid, w, lds);
+    between(1);
+    fft8_pass_pre<LOG2M, RL, 64, DIR, true, 3, NW>(u, tid, w, lds);
+  } else {
+    fft8_pass_pre<LOG2M, 8, 8, DIR, false, 0, NW>(u, tid, w, lds);
+    between(1);
+    fft8_pass_pre<LOG2M, 8, 64, DIR, false, 3, NW>(u, tid, w, lds);
+    between(2);
+    fft8_pass_pre<LOG2M, RL, 512, DIR, true, 6, NW>(u, tid, w, lds);
+  }
+}
+
 // `active`: threads that hold points (tid < M/8); every thread of the workgroup must call (barriers)
 template <int LOG2M, int DIR, bool TWGEN = (RSMP_TWGEN_DEFAULT != 0)>
 __device__ __forceinline__ void fft8_regs_masked(c64 (&u)[8], int tid, bool active, const double2 *__restrict__ tw, double *lds)

@@ -36,9 +36,16 @@
 #ifndef RSMP_BUFSTORE
 #define RSMP_BUFSTORE 1
 #endif
+// RSMP_EXP_SKIP (same rules): phase ablations of the lean kernel for the cycle budget of DESIGN.md 5a -- bit 0 no polyphase
+// rounds, 1 no inverse transform, 2 no forward transform, 3 no output stores, 4 no polyphase LDS reads (first tile's samples
+// reused), 5 no MFMAs (loads and stores stay), 6 no sample image / seam writes, 7 no G loads, 8 no input loads
 // RSMP_EXP_TAB / RSMP_EXP_LINEAR / RSMP_EXP_HALFMFMA (knobs.hpp; -DRSMP_EXPERIMENTS builds only, WRONG results): bit 0 = every
 // coefficient tile is group 0's, bit 1 = every G value is slot 0's (the loads stay, their L1 misses go: upper bounds of what
 // smaller / shared tables could buy); lane-linear window reads; 6 of every 14 MFMAs removed
+// forward transform (FWD8 form) on twiddles loaded next to the block's input, G issued two passes before it is needed
+#ifndef RSMP_FWD_PRETW
+#define RSMP_FWD_PRETW 1
+#endif
 #ifndef RSMP_PRIO
 #define RSMP_PRIO 0
 #endif
@@ -94,7 +101,10 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   const int nm1 = a.n - 1;
 
   if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-  // RSMP_STAMPS=1: per-phase cycle sums of wave 0 (s_memtime) in one workgroup of 64, printed when the handle closes
+  // Builds with -DRSMP_STAMPS_BUILD (tools/build_variant.sh) + RSMP_STAMPS=1 in the environment: per-phase cycle sums of wave 0
+  // (s_memtime) in one workgroup of 64, printed when the handle closes.  The product build has no trace of it: the stamp
+  // points were branches (and scheduling barriers) in every workgroup.
+#ifdef RSMP_STAMPS_BUILD
   const bool stamping = a.stamps && (blockIdx.x & 63) == 5;
   unsigned long long tstamp = stamping ? __builtin_readcyclecounter() : 0;
 #define RSMP_STAMP(slot)                                          \
@@ -103,6 +113,9 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     if (tid == 0) atomicAdd(a.stamps + (slot), now - tstamp);      \
     tstamp = now;                                                  \
   }
+#else
+#define RSMP_STAMP(slot)
+#endif
 
   // ---------------------------------------------------------------- load the block (fp32 -> fp64)
   // L = 2 (FWD8): the forward transform has half the points of the inverse one and runs 8 points per thread on ALL
@@ -112,9 +125,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   constexpr int NLD = FWD8 ? 8 : 16, TL = FWD8 ? T : TF; // points per loading thread, loading threads
   c64 v[16];
   c64 u8[8];
+  constexpr bool PRETW = FWD8 && RSMP_FWD_PRETW;
+  double2 wf[PRETW ? fft8_tw_regs(LOG2P) : 1];
+  if constexpr (PRETW) fft8_tw_load<LOG2P>(wf, tid, a.d.tw_fwd8); // in flight together with the input loads below
   {
     const long long e0 = B * a.d.q;
-    const bool ld_active = FWD8 || fwd_active;
+    const bool ld_active = (FWD8 || fwd_active) && !(RSMP_EXP_SKIP & 256);
+    if (RSMP_EXP_SKIP & 256) {
+#pragma unroll
+      for (int s = 0; s < NLD; ++s) (FWD8 ? u8[s & 7] : v[s]) = {1e-3 * tid, 1e-3 * s};
+    }
     if (e0 >= io.in_abs0) { // uniform: the whole block lies in the caller's buffer
       const float2 *p2 = reinterpret_cast<const float2 *>(io.in + strm * io.in_stream_stride + (e0 - io.in_abs0) * io.nch + 2 * pin);
       if (ld_active) {
@@ -137,10 +157,26 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   RSMP_STAMP(0)
   // ---------------------------------------------------------------- FFT-FIR (as fused_kernel)
   if constexpr (FWD8) {
-    double2 g[16]; // in flight during the whole forward transform
+    double2 g[16];
+    if constexpr ((RSMP_EXP_SKIP & 4) != 0) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + (RSMP_EXP_TAB & 2 ? 0 : s * T));
-    fft8_regs<LOG2P, -1, RSMP_TWGEN != 0>(u8, tid, a.d.tw_fwd8, lds);
+      for (int s = 0; s < 16; ++s) g[s] = (RSMP_EXP_SKIP & 128) ? make_double2(1e-3 * s, 1e-4 * tid) : load_g(Gp + tid + s * T);
+      if constexpr (PRETW) {
+#pragma unroll
+        for (int i = 0; i < fft8_tw_regs(LOG2P); ++i) u8[i & 7].x += wf[i].x * 1e-30; // keep the loads alive
+      }
+    } else if constexpr (PRETW) {
+      fft8_regs_pre<LOG2P, -1>(u8, tid, wf, lds, [&](int p) {
+        if (p == 1) { // two passes (two LDS round trips) ahead of the multiplication
+#pragma unroll
+          for (int s = 0; s < 16; ++s) g[s] = (RSMP_EXP_SKIP & 128) ? make_double2(1e-3 * s, 1e-4 * tid) : load_g(Gp + tid + (RSMP_EXP_TAB & 2 ? 0 : s * T));
+        }
+      });
+    } else { // G in flight during the whole forward transform
+#pragma unroll
+      for (int s = 0; s < 16; ++s) g[s] = load_g(Gp + tid + (RSMP_EXP_TAB & 2 ? 0 : s * T));
+      fft8_regs<LOG2P, -1, RSMP_TWGEN != 0>(u8, tid, a.d.tw_fwd8, lds);
+    }
     RSMP_STAMP(1)
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = cmul(u8[s & 7], c64{g[s].x, g[s].y});
@@ -183,7 +219,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   }
   }
   RSMP_STAMP(2)
-  fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
+  if constexpr (!(RSMP_EXP_SKIP & 2)) fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
   RSMP_STAMP(3)
 
   // ---------------------------------------------------------------- stage-1 samples -> LDS (round A) and seam ring
@@ -198,9 +234,10 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     for (int s = 0; s < 16; ++s) {
       const int n = tid + s * T;
       const bool whole = (s + 1) * T <= V;                 // every sample of this slot is valid
-      if (s < kSA || s == kSA) {
+      if ((s < kSA || s == kSA) && !(RSMP_EXP_SKIP & 64)) {
         if (s < kSA ? (whole || n < V) : (tid < kPad && n < V)) smp[n] = make_double2(v[s].x, v[s].y);
       }
+      if (RSMP_EXP_SKIP & 64) continue;
       if (s == 0 && tid < nm1) {
         seamA[tid] = v[0].x;
         seamB[tid] = v[0].y;
@@ -263,9 +300,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #endif
     const int step4 = 4 * step, pl4 = 4 * pl;
 
-    double cc[KS], cn[KS]; // coefficient tiles: current group, next group (in flight)
-    int qc, qn = 0;
-    auto load_tile = [&](int gg, double (&c_)[KS], int &q_) {
+    // Coefficient tiles: current group, next group (in flight).  The window start of a group comes with its tile (odd KS: spare
+    // half of the last 16-byte element) and stays a double until the group becomes current, so that nothing waits for the
+    // tile load at the point where it is issued.
+    // (Measured and NOT kept, round 3: two register sets used alternately group by group, all four (set, sample buffer)
+    // combinations spelled out so that no set is ever copied and no s_waitcnt vmcnt(0) sits behind the prefetch -- 168 VGPRs
+    // with 19 spilled across round A, 2.37 against 1.96 ms.  The kernel has no registers to spare at three workgroups per CU.)
+    double cc[KS], cn[KS];
+    double qcd = 0.0, qnd = 0.0;
+    int qci = 0, qni = 0;
+    auto load_tile = [&](int gg, double (&c_)[KS], double &qd_, int &qi_) {
       constexpr int KSP = (KS + 1) / 2;
       const double2 *cp = cfm_lane + (RSMP_EXP_TAB & 1 ? 0 : gg) * (KSP * 64); // uniform offset; two k-steps per 16-byte load
 #pragma unroll
@@ -273,12 +317,13 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         const double2 d = cp[s2 * 64];
         c_[2 * s2] = d.x;
         if (2 * s2 + 1 < KS) c_[2 * s2 + 1] = d.y;
-        else q_ = (int)d.y; // odd KS: the spare half carries the window start
+        else qd_ = d.y;
       }
-      if (!(KS & 1)) q_ = qtab_lane[gg * 4];
+      if (!(KS & 1)) qi_ = qtab_lane[gg * 4];
     };
-    load_tile(g, cc, qc);
-    if (g < g_last) load_tile(g + 1, cn, qn);
+    auto qof = [&](double qd_, int qi_) { return (KS & 1) ? (int)qd_ : qi_; };
+    load_tile(g, cc, qcd, qci);
+    load_tile(min(g + 1, ngrp - 1), cn, qnd, qni); // (unconditional, clamped: see the group switch below)
 
     double2 x0[KS], x1[KS];
     auto fill = [&](double2 (&x)[KS], int q, int cstep) {
@@ -291,6 +336,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #pragma unroll
       for (int s = 0; s < KS; ++s) x[s] = xp[4 * s];
     };
+    int qc = qof(qcd, qci);
     fill(x0, qc, c);
 
     int left = t1 - t0;
@@ -302,12 +348,22 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         gnext = g + 1;
       }
       const bool switch_group = gnext != g && left > 1;
-      fill(xn, switch_group ? qn : qc, left > 1 ? cnext : c); // after the last tile: a harmless re-read
+      if (switch_group) { // uniform.  Volatile so that it STAYS a branch: as a select the conversion runs in every tile and the
+                          // tile right behind a switch waits for the tile load that was just issued
+        if constexpr (KS & 1) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(qc) : "v"(qnd));
+        else asm volatile("v_mov_b32 %0, %1" : "=v"(qc) : "v"(qni));
+      }
+      if constexpr (!(RSMP_EXP_SKIP & 16)) fill(xn, qc, left > 1 ? cnext : c); // after the last tile: a harmless re-read
       double accA = 0.0, accB = 0.0;
 #pragma unroll
       for (int s = 0; s < (RSMP_EXP_HALFMFMA ? 3 : KS); ++s) { // RSMP_EXP_HALFMFMA: timing experiment only (WRONG results)
-        accA = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].x, accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], xc[s].y, accB, 0, 0, 0);
+        if constexpr ((RSMP_EXP_SKIP & 32) != 0) { // no MFMAs: one add per operand keeps the loads alive
+          accA += cc[s] + ((RSMP_EXP_SKIP & 16) ? x0[s].x : xc[s].x);
+          accB += (RSMP_EXP_SKIP & 16) ? x0[s].y : xc[s].y;
+        } else {
+          accA = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], (RSMP_EXP_SKIP & 16) ? x0[s].x : xc[s].x, accA, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f64_4x4x4f64(cc[s], (RSMP_EXP_SKIP & 16) ? x0[s].y : xc[s].y, accB, 0, 0, 0);
+        }
       }
 #if RSMP_EXP_HALFMFMA
 #pragma unroll
@@ -331,6 +387,9 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         // the last (partial) group needs a select
         const unsigned off = (16 * g + rloc < pl) ? (unsigned)__mul24(ib, frame_bytes) : 0xffffffffu; // |ib| < 2^23: full-rate multiply
         const rsmp_v2u d = {__float_as_uint((float)accA), __float_as_uint((float)accB)};
+        if constexpr ((RSMP_EXP_SKIP & 8) != 0) { // no stores: only a result nobody produces would be written
+          if (accA == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (int)off, 0, 0);
+        } else
         __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (int)off, 0, 0);
       }
 #else
@@ -339,9 +398,14 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #endif
       if (switch_group) { // uniform
 #pragma unroll
-        for (int s = 0; s < KS; ++s) cc[s] = cn[s];
-        qc = qn;
-        if (gnext < g_last) load_tile(gnext + 1, cn, qn);
+        for (int s = 0; s < KS; ++s) asm volatile("v_mov_b64 %0, %1" : "=v"(cc[s]) : "v"(cn[s]));
+        __builtin_amdgcn_sched_barrier(0);
+        // The copy is spelled out and fenced so that `cn`'s registers are dead before the next tile load is issued and the load
+        // can land in them directly.  (As plain assignments the copy materialises at the END of the block, behind the load:
+        // the compiler then lands the tile in scratch registers and moves it into `cn` behind an s_waitcnt vmcnt(0) right
+        // after issuing it -- a full L2 round trip, and a drain of the output stores, at every group switch.)  The load is
+        // unconditional for the same reason (clamped group index: past the wave's last group a harmless re-read).
+        load_tile(min(gnext + 1, ngrp - 1), cn, qnd, qni);
       }
       g = gnext;
       c = cnext;
@@ -355,7 +419,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     }
   };
 
-  const bool run = fb.cnt > 0;
+  const bool run = fb.cnt > 0 && !(RSMP_EXP_SKIP & 1);
   if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
   if (RSMP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   // round A: periods whose windows end inside the samples written above
@@ -368,14 +432,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #pragma unroll
     for (int s = kSB0; s < 16; ++s) {
       const int n = tid + s * T;
-      if (n < V) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
+      if (n < V && !(RSMP_EXP_SKIP & 64)) l2[n - kSB0 * T] = make_double2(v[s].x, v[s].y);
     }
     if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
   }
   __syncthreads();
   if (run && fb.KA < fb.K) poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * KS);
   RSMP_STAMP(5)
+#ifdef RSMP_STAMPS_BUILD
   if (stamping && tid == 0) atomicAdd(a.stamps + 7, 1ull);
+#endif
 #undef RSMP_STAMP
 }
 

@@ -22,7 +22,7 @@
 #if (defined(RSMP_EXP_TAB) && RSMP_EXP_TAB) || (defined(RSMP_EXP_LINEAR) && RSMP_EXP_LINEAR) ||       \
     (defined(RSMP_EXP_HALFMFMA) && RSMP_EXP_HALFMFMA) || (defined(RSMP_EXP_TWK0) && RSMP_EXP_TWK0) || \
     (defined(RSMP_EXP_TWLOAD) && RSMP_EXP_TWLOAD) || (defined(RSMP_EXP_NOBAR) && RSMP_EXP_NOBAR) ||   \
-    (defined(RSMP_DFTX_SKIP) && RSMP_DFTX_SKIP)
+    (defined(RSMP_DFTX_SKIP) && RSMP_DFTX_SKIP) || (defined(RSMP_EXP_SKIP) && RSMP_EXP_SKIP)
 #error "wrong-result experiment switches need -DRSMP_EXPERIMENTS (tools/build_variant.sh); the product build never sets them"
 #endif
 #undef RSMP_EXP_TAB
@@ -32,6 +32,8 @@
 #undef RSMP_EXP_TWLOAD
 #undef RSMP_EXP_NOBAR
 #undef RSMP_DFTX_SKIP
+#undef RSMP_EXP_SKIP
+#define RSMP_EXP_SKIP 0
 #define RSMP_EXP_TAB 0
 #define RSMP_EXP_LINEAR 0
 #define RSMP_EXP_HALFMFMA 0
@@ -60,6 +62,9 @@
 #endif
 #ifndef RSMP_DFTX_SKIP
 #define RSMP_DFTX_SKIP 0
+#endif
+#ifndef RSMP_EXP_SKIP
+#define RSMP_EXP_SKIP 0
 #endif
 #endif
 

@@ -119,7 +119,7 @@ def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
     n = r.isamp_max
     x = bench.lcg_noise_device(torch, S, n, nch, 12345, "cuda")
     r.set_stream(torch.cuda.current_stream().cuda_stream)
-    cap = int(n * fo / fi) + 8192
+    cap = int(n * fo / fi) + 65536  # a push's output varies by a block or two of the last stage around the mean
     ys, ogs = [], []
     for _ in range(2):
         y = torch.zeros((S, cap, nch), device="cuda")
