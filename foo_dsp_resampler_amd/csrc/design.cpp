@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 
 namespace rsmp {
 
@@ -138,72 +139,114 @@ std::vector<double> design_lowpass(double Fp, double Fs, double Fn, double att, 
   return h;
 }
 
+// lsx_fir_to_phase (effects_i_dsp.c:181-278) in EXTENDED precision (x87 long double: 64-bit significand).
+//
+// The construction takes the logarithm of the filter's spectrum; in the stop band (-180 dB for the Best filters) that
+// amplifies the rounding of whatever FFT produced the spectrum by ~1e9, so in plain fp64 the designed taps are an accident of
+// one FFT's rounding, reproducible to ~1e-7 of the peak only (round 2 measured 1.1e-6 ... 4.2e-6 relative RMS at the output
+// between this library and the oracle, whose FFTs differ; the reference's own Ooura transform would give a third answer).
+// Every transform, logarithm, exponential and sine / cosine below therefore runs on long double and the taps are rounded to
+// double once, at the end: two independent implementations of the same mathematics (this one and the oracle's) then agree
+// to a few fp64 ulps of the peak, and the filter no longer depends on an FFT's rounding.  Against the reference itself
+// the tolerance stays what fp64 Ooura arithmetic makes it: inherent ~1e-6 at the output, unpinned.
+namespace {
+typedef long double ld;
+typedef std::complex<ld> cld;
+const ld kPiL = 3.14159265358979323846264338327950288L;
+
+// iterative radix-2 transform on long double, twiddles from a table of cosl / sinl (one entry per distinct angle)
+void fft_ld(std::vector<cld> &a, int sign)
+{
+  const size_t n = a.size();
+  int bits = 0;
+  while ((size_t(1) << bits) < n) ++bits;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t r = bit_reverse(unsigned(i), bits);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  std::vector<cld> w(n / 2 ? n / 2 : 1);
+  for (size_t k = 0; k < n / 2; ++k) {
+    const ld th = 2 * kPiL * ld(k) / ld(n);
+    w[k] = cld(cosl(th), sign * sinl(th));
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len / 2, stride = n / len;
+    for (size_t base = 0; base < n; base += len)
+      for (size_t k = 0; k < half; ++k) {
+        const cld t = a[base + k + half] * w[k * stride], u = a[base + k];
+        a[base + k] = u + t;
+        a[base + k + half] = u - t;
+      }
+  }
+}
+} // namespace
+
 void to_phase(std::vector<double> &h, int &post_len, double phase)
 {
-  const double blend = (phase > 50 ? 100 - phase : phase) / 50; // 0: minimum phase ... 1: linear
+  const ld blend = ld((phase > 50 ? 100 - phase : phase) / 50); // 0: minimum phase ... 1: linear
   int len = int(h.size());
   int W = 32;
   for (int i = len; i > 1; i >>= 1) W <<= 1;
   const int half = W / 2;
 
-  std::vector<cplx> buf(W);
-  for (int i = 0; i < len; ++i) buf[i] = h[i];
-  fft_inplace(buf, +1);
-  buf[0] = cplx(buf[0].real(), 0); // the reference's packed real transform has no imaginary
-  buf[half] = cplx(buf[half].real(), 0); // part at DC / Nyquist
+  std::vector<cld> buf(W);
+  for (int i = 0; i < len; ++i) buf[i] = cld(ld(h[i]), 0);
+  fft_ld(buf, +1);
+  buf[0] = cld(buf[0].real(), 0);       // the reference's packed real transform has no imaginary
+  buf[half] = cld(buf[half].real(), 0); // part at DC / Nyquist
 
   // count phase wraps and take the log magnitude, bins 0..W/2 (effects_i_dsp.c:206-224)
-  std::vector<double> wraps(half + 1), logmag(half + 1);
-  double prev2 = 0, cum2 = 0, prev1 = 0, cum1 = 0;
+  std::vector<ld> wraps(half + 1), logmag(half + 1);
+  ld prev2 = 0, cum2 = 0, prev1 = 0, cum1 = 0;
   for (int k = 0; k <= half; ++k) {
-    const double re = buf[k].real(), im = buf[k].imag();
-    double angle = std::atan2(im, re);
-    double span = 2 * kPi, delta = angle - prev2;
-    double adj = span * ((delta < -span * .7) - (delta > span * .7));
+    const ld re = buf[k].real(), im = buf[k].imag();
+    ld angle = atan2l(im, re);
+    ld span = 2 * kPiL, delta = angle - prev2;
+    ld adj = span * ld((delta < -span * .7L) - (delta > span * .7L));
     prev2 = angle;
     cum2 += adj;
     angle += cum2;
-    span = kPi;
+    span = kPiL;
     delta = angle - prev1;
-    adj = span * ((delta < -span * .7) - (delta > span * .7));
+    adj = span * ld((delta < -span * .7L) - (delta > span * .7L));
     prev1 = angle;
-    cum1 += std::fabs(adj);
+    cum1 += fabsl(adj);
     wraps[k] = cum1;
-    const double mag = std::sqrt(re * re + im * im);
-    logmag[k] = mag ? std::log(mag) : -26;
+    const ld mag = sqrtl(re * re + im * im);
+    logmag[k] = mag != 0 ? logl(mag) : -26;
   }
 
   // real cepstrum, folded onto its causal half
-  for (int k = 0; k <= half; ++k) buf[k] = logmag[k];
-  for (int k = 1; k < half; ++k) buf[W - k] = logmag[k];
-  fft_inplace(buf, -1);
-  std::vector<double> cep(W);
+  for (int k = 0; k <= half; ++k) buf[k] = cld(logmag[k], 0);
+  for (int k = 1; k < half; ++k) buf[W - k] = cld(logmag[k], 0);
+  fft_ld(buf, -1);
+  std::vector<ld> cep(W);
   for (int i = 0; i < W; ++i) cep[i] = buf[i].real() / W;
   for (int i = 1; i < half; ++i) {
     cep[i] *= 2;
     cep[i + half] = 0;
   }
-  for (int i = 0; i < W; ++i) buf[i] = cep[i];
-  fft_inplace(buf, +1); // real part: log magnitude, imaginary part: minimum phase
+  for (int i = 0; i < W; ++i) buf[i] = cld(cep[i], 0);
+  fft_ld(buf, +1); // real part: log magnitude, imaginary part: minimum phase
 
   // blend the phase toward linear and rebuild the (Hermitian) spectrum (effects_i_dsp.c:236-246)
-  std::vector<cplx> spec(W);
-  spec[0] = std::exp(buf[0].real());
-  spec[half] = std::exp(buf[half].real());
+  std::vector<cld> spec(W);
+  spec[0] = cld(expl(buf[0].real()), 0);
+  spec[half] = cld(expl(buf[half].real()), 0);
   for (int k = 1; k < half; ++k) {
-    const double ph = blend * (2.0 * k) / W * wraps[half] + (1 - blend) * (buf[k].imag() + wraps[k]) - wraps[k];
-    const double mag = std::exp(buf[k].real());
-    spec[k] = cplx(mag * std::cos(ph), mag * std::sin(ph));
+    const ld ph = blend * (2 * ld(k)) / W * wraps[half] + (1 - blend) * (buf[k].imag() + wraps[k]) - wraps[k];
+    const ld mag = expl(buf[k].real());
+    spec[k] = cld(mag * cosl(ph), mag * sinl(ph));
     spec[W - k] = std::conj(spec[k]);
   }
-  fft_inplace(spec, -1);
+  fft_ld(spec, -1);
   std::vector<double> imp(W);
-  for (int i = 0; i < W; ++i) imp[i] = spec[i].real() / W;
+  for (int i = 0; i < W; ++i) imp[i] = double(spec[i].real() / W); // the one rounding to fp64
 
   // locate the impulse peak (effects_i_dsp.c:251-260)
   int peak = 0;
   double run = 0, best = 0;
-  const int search = int(wraps[half] / kPi + .5);
+  const int search = int(double(wraps[half]) / kPi + .5);
   for (int i = 0; i <= search; ++i) {
     run += imp[i];
     if (std::fabs(run) > std::fabs(best)) {
@@ -213,14 +256,15 @@ void to_phase(std::vector<double> &h, int &post_len, double phase)
   }
   while (peak && std::fabs(imp[peak - 1]) > std::fabs(imp[peak]) && imp[peak - 1] * imp[peak] > 0) --peak;
 
+  const double bl = double(blend);
   int begin;
-  if (blend == 0)
+  if (bl == 0)
     begin = 0;
-  else if (blend == 1)
+  else if (bl == 1)
     begin = peak - len / 2;
   else {
-    begin = int((.997 - (2 - blend) * .22) * len + .5);
-    int end = int((.997 + (0 - blend) * .22) * len + .5);
+    begin = int((.997 - (2 - bl) * .22) * len + .5);
+    int end = int((.997 + (0 - bl) * .22) * len + .5);
     begin = peak - (begin & ~3);
     end = peak + 1 + ((end + 3) & ~3);
     len = end - begin;

@@ -269,8 +269,135 @@ double *orc_design_lpf(double Fp, double Fs, double Fn, double att, int *num_tap
 
 static double safe_log(double x) { return x ? log(x) : -26; } /* :173-179 */
 
-/* :181-278 (cepstral minimum-phase construction, then interpolation toward linear phase) */
+/* ---- extended-precision form of the same construction (the default) --------------------------------------
+ * In fp64 the function below is reproducible to ~1e-7 of the filter's peak only: it takes the log of a -180 dB stop band, which
+ * amplifies the rounding of whichever FFT produced the spectrum by ~1e9, so two correct fp64 implementations (this oracle's,
+ * the product's, the reference's Ooura transform) design three slightly different filters.  Here every transform, log, exp,
+ * sin / cos and atan2 runs on long double (x87, 64-bit significand) and the taps are rounded to double once at the end; the
+ * product's design.cpp does the same with code of its own, and the two then agree to a few ulps of the peak
+ * (tests/test_host_plan.py::test_phase_tables_agree_in_extended_precision).  orc_set_phase_arith(1) selects the fp64 statement
+ * that follows the reference line by line (orc_fir_to_phase_ref64): the gap between the two IS the reference's inherent
+ * irreproducibility, ~1e-6 relative RMS at the output -- "parity unpinned" for phase != 50, see DESIGN.md. */
+typedef long double orc_ld;
+static const orc_ld ORC_PIL = 3.14159265358979323846264338327950288L;
+
+/* In-place decimation in FREQUENCY (Gentleman-Sande butterflies, bit reversal at the end) on split re / im arrays, twiddles
+ * straight from cosl / sinl; n a power of two.  (The product's design.cpp uses decimation in time from a twiddle table: the two
+ * round differently, which is the point -- what they agree on does not depend on one transform's rounding.) */
+static void fft_ld(orc_ld *re, orc_ld *im, int n, int sign)
+{
+  int len, base, k, i, j;
+  for (len = n; len >= 2; len >>= 1) {
+    const int half = len / 2;
+    for (k = 0; k < half; ++k) {
+      const orc_ld th = 2 * ORC_PIL * (orc_ld)k / (orc_ld)len, c = cosl(th), s = sign * sinl(th);
+      for (base = 0; base < n; base += len) {
+        const int a = base + k, b = a + half;
+        const orc_ld dr = re[a] - re[b], di = im[a] - im[b];
+        re[a] += re[b]; im[a] += im[b];
+        re[b] = dr * c - di * s; im[b] = dr * s + di * c;
+      }
+    }
+  }
+  for (i = 0, j = 0; i < n; ++i) { /* bit reversal */
+    int bit;
+    if (i < j) { orc_ld t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    for (bit = n >> 1; bit && (j & bit); bit >>= 1) j ^= bit;
+    j |= bit;
+  }
+}
+
+static int g_phase_ref64 = 0;
+void orc_set_phase_arith(int ref64) { g_phase_ref64 = ref64; }
+void orc_fir_to_phase_ref64(double **h, int *len, int *post_len, double phase);
+
+/* effects_i_dsp.c:181-278, same steps and constants, long double inside */
 void orc_fir_to_phase(double **h, int *len, int *post_len, double phase)
+{
+  const double phase1 = (phase > 50 ? 100 - phase : phase) / 50;
+  const orc_ld p1 = phase1;
+  int i, wlen, half, begin, end, peak = 0;
+  orc_ld *re, *im, *wraps;
+  double *imp, imp_sum = 0, peak_imp_sum = 0;
+  orc_ld prev2 = 0, cum2 = 0, prev1 = 0, cum1 = 0;
+
+  if (g_phase_ref64) { orc_fir_to_phase_ref64(h, len, post_len, phase); return; }
+  for (i = *len, wlen = 2 * 2 * 8; i > 1; wlen <<= 1, i >>= 1) {}
+  half = wlen / 2;
+  re = (orc_ld *)calloc((size_t)wlen, sizeof(orc_ld));
+  im = (orc_ld *)calloc((size_t)wlen, sizeof(orc_ld));
+  wraps = (orc_ld *)malloc(sizeof(orc_ld) * (size_t)(half + 1));
+  imp = (double *)malloc(sizeof(double) * (size_t)wlen);
+
+  for (i = 0; i < *len; ++i) re[i] = (*h)[i];
+  fft_ld(re, im, wlen, +1);
+  im[0] = 0; im[half] = 0; /* the packed real transform of the reference carries no imaginary part at DC / Nyquist */
+
+  for (i = 0; i <= half; ++i) { /* :206-224 */
+    orc_ld angle = atan2l(im[i], re[i]);
+    orc_ld detect = 2 * ORC_PIL;
+    orc_ld delta = angle - prev2;
+    orc_ld adjust = detect * (orc_ld)((delta < -detect * .7L) - (delta > detect * .7L));
+    orc_ld mag;
+    prev2 = angle;
+    cum2 += adjust;
+    angle += cum2;
+    detect = ORC_PIL;
+    delta = angle - prev1;
+    adjust = detect * (orc_ld)((delta < -detect * .7L) - (delta > detect * .7L));
+    prev1 = angle;
+    cum1 += fabsl(adjust);
+    wraps[i] = cum1;
+    mag = sqrtl(re[i] * re[i] + im[i] * im[i]);
+    re[i] = mag != 0 ? logl(mag) : -26;
+    im[i] = 0;
+  }
+  for (i = 1; i < half; ++i) { re[wlen - i] = re[i]; im[wlen - i] = 0; } /* Hermitian image of a real, even log spectrum */
+  fft_ld(re, im, wlen, -1);
+  for (i = 0; i < wlen; ++i) { re[i] /= wlen; im[i] = 0; } /* real cepstrum */
+  for (i = 1; i < half; ++i) { re[i] *= 2; re[i + half] = 0; } /* :231-234 */
+  fft_ld(re, im, wlen, +1); /* re: log magnitude, im: minimum phase */
+
+  { /* :236-246 */
+    const orc_ld top = wraps[half];
+    orc_ld m0 = expl(re[0]), mh = expl(re[half]);
+    for (i = 1; i < half; ++i) {
+      const orc_ld ph = p1 * (orc_ld)(2 * i) / wlen * top + (1 - p1) * (im[i] + wraps[i]) - wraps[i];
+      const orc_ld mag = expl(re[i]);
+      re[i] = mag * cosl(ph); im[i] = mag * sinl(ph);
+      re[wlen - i] = re[i]; im[wlen - i] = -im[i];
+    }
+    re[0] = m0; im[0] = 0; re[half] = mh; im[half] = 0;
+  }
+  fft_ld(re, im, wlen, -1);
+  for (i = 0; i < wlen; ++i) imp[i] = (double)(re[i] / wlen); /* the one rounding to fp64 */
+
+  for (i = 0; i <= (int)((double)wraps[half] / M_PI + .5); ++i) { /* :251-260 */
+    imp_sum += imp[i];
+    if (fabs(imp_sum) > fabs(peak_imp_sum)) { peak_imp_sum = imp_sum; peak = i; }
+  }
+  while (peak && fabs(imp[peak - 1]) > fabs(imp[peak]) && imp[peak - 1] * imp[peak] > 0) --peak;
+
+  if (!phase1)
+    begin = 0;
+  else if (phase1 == 1)
+    begin = peak - *len / 2;
+  else {
+    begin = (int)((.997 - (2 - phase1) * .22) * *len + .5);
+    end = (int)((.997 + (0 - phase1) * .22) * *len + .5);
+    begin = peak - (begin & ~3);
+    end = peak + 1 + ((end + 3) & ~3);
+    *len = end - begin;
+    *h = (double *)realloc(*h, sizeof(double) * (size_t)*len);
+  }
+  for (i = 0; i < *len; ++i)
+    (*h)[i] = imp[(begin + (phase > 50 ? *len - 1 - i : i) + wlen) & (wlen - 1)];
+  *post_len = phase > 50 ? peak - begin : begin + *len - (peak + 1);
+  free(re); free(im); free(wraps); free(imp);
+}
+
+/* :181-278 (cepstral minimum-phase construction, then interpolation toward linear phase), fp64 as in the reference */
+void orc_fir_to_phase_ref64(double **h, int *len, int *post_len, double phase)
 {
   double *wraps, *w, phase1 = (phase > 50 ? 100 - phase : phase) / 50;
   int i, wlen, begin, end, peak = 0;

@@ -88,7 +88,9 @@ int orc_dft_length(int num_taps);                                 /* :64-73 */
 double orc_kaiser_beta(double att, double tr_bw);                 /* :83-108 */
 double *orc_design_lpf(double Fp, double Fs, double Fn, double att, int *num_taps, int k,
                        double beta);                              /* :137-171 (malloc'd; caller frees with orc_free) */
-void orc_fir_to_phase(double **h, int *len, int *post_len, double phase); /* :181-278 */
+void orc_fir_to_phase(double **h, int *len, int *post_len, double phase); /* :181-278, long double inside (see rate_oracle.c) */
+void orc_fir_to_phase_ref64(double **h, int *len, int *post_len, double phase); /* :181-278 in the reference's own fp64 */
+void orc_set_phase_arith(int ref64); /* 1: orc_fir_to_phase runs the fp64 statement (process-wide; default 0) */
 void orc_free(void *p);
 
 /* real FFT with the reference's packing/scaling conventions (fft-double/fft4g_dbl.c:26-62):

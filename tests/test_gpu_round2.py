@@ -133,10 +133,10 @@ def test_dft_stage_upsampling_by_8_or_more(fi, fo):
 
 
 def test_non_linear_phase_measured_parity():
-    """phase != 50 goes through the cepstral minimum-phase construction (effects_i_dsp.c:181-278), which amplifies
-    the fp64 rounding differences between two correct FFTs; the measured relative RMS per phase is written to
-    gpurun_out/phase_parity.json and must stay within 4x the value committed in profiles/r02_phase_parity.json
-    (round 2's measurement of the same case: 5.5e-7 at phase 25/75 ... 4.2e-6 for 96k->44.1k at phase 0/100)."""
+    """phase != 50 goes through the cepstral minimum-phase construction (effects_i_dsp.c:181-278).  Round 2 measured 5.5e-7 ...
+    4.2e-6 relative RMS against the oracle here (profiles/r02_phase_parity.json): two fp64 FFTs, two filters.  With the
+    construction in extended precision on both sides every case meets the normal bar; the measured values go to
+    gpurun_out/phase_parity.json (tracked copy: profiles/r03_phase_parity.json)."""
     out = {}
     for phase in (0.0, 25.0, 75.0, 100.0):
         for fi, fo in ((44100, 48000), (44100, 96000), (96000, 44100)):
@@ -149,11 +149,8 @@ def test_non_linear_phase_measured_parity():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "phase_parity.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    # bar: 4 x what round 2 measured for the same case (profiles/r02_phase_parity.json: 5.5e-7 ... 4.2e-6)
-    with open(os.path.join(ROOT, "profiles", "r02_phase_parity.json")) as f:
-        measured = json.load(f)
     for k, v in out.items():
-        assert v["rel_rms"] <= 4.0 * measured[k]["rel_rms"], (k, v, measured[k])
+        assert v["max_ulp"] <= 1.0 and v["rel_rms"] <= 1e-7, (k, v)
 
 
 def test_long_blocks_many_items_per_push():
