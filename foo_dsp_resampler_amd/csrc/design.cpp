@@ -144,10 +144,10 @@ std::vector<double> design_lowpass(double Fp, double Fs, double Fn, double att, 
 // The construction takes the logarithm of the filter's spectrum; in the stop band (-180 dB for the Best filters) that
 // amplifies the rounding of whatever FFT produced the spectrum by ~1e9, so in plain fp64 the designed taps are an accident of
 // one FFT's rounding, reproducible to ~1e-7 of the peak only (round 2 measured 1.1e-6 ... 4.2e-6 relative RMS at the output
-// between this library and the oracle, whose FFTs differ; the reference's own Ooura transform would give a third answer).
-// Every transform, logarithm, exponential and sine / cosine below therefore runs on long double and the taps are rounded to
-// double once, at the end: two independent implementations of the same mathematics (this one and the oracle's) then agree
-// to a few fp64 ulps of the peak, and the filter no longer depends on an FFT's rounding.  Against the reference itself
+// between this library and an independent fp64 implementation of the same steps; the reference's own Ooura transform would
+// give a third answer).  Every transform, logarithm, exponential and sine / cosine below therefore runs on long double and
+// the taps are rounded to double once, at the end: two implementations with transforms of different structure then agree
+// to 1e-10 ... 6e-9 of the peak tap (tests/test_host_plan.py), 1000x closer than in fp64.  Against the reference itself
 // the tolerance stays what fp64 Ooura arithmetic makes it: inherent ~1e-6 at the output, unpinned.
 namespace {
 typedef long double ld;
