@@ -94,7 +94,11 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
   const long long B = a.d.B0 + bl;
   const int hp = io.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+#if defined(RSMP_EXPERIMENTS) && defined(RSMP_VCONST) // what a block length known at compile time would buy (553-tap filters: 3544)
+  const int V = RSMP_VCONST;
+#else
   const int V = a.d.V;
+#endif
   const bool fwd_active = tid < TF;
   const double2 *__restrict__ Gp = a.d.G;
   double2 *smp = reinterpret_cast<double2 *>(lds) + kPad; // smp[n] = (channel A, channel B) sample n of the block
@@ -228,26 +232,21 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     const int slot = (int)(B & a.seam_mask);
     double *seamA = a.seam + ((long long)(slot * (a.d.C + 1) + ca) * 2) * 32;
     double *seamB = a.seam + ((long long)(slot * (a.d.C + 1) + cb) * 2) * 32;
-    // (the slot tests are wave-uniform: only the slots that can hold a block edge carry per-lane tests and seam stores)
-    const int tail0 = V - nm1; // first sample of the block's tail
+    // The head of the block goes to the seam ring from registers (slot 0); the tail is picked up from the LDS image below
+    // (store_tail), where it is 23 consecutive elements -- out of registers it took per-lane range tests and a pair of
+    // conditional global stores in every one of the 16 unrolled slots (V is a run-time value): ~300 scalar and ~150 vector
+    // instructions per wave for 46 doubles.
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s <= kSA; ++s) {
       const int n = tid + s * T;
       const bool whole = (s + 1) * T <= V;                 // every sample of this slot is valid
-      if ((s < kSA || s == kSA) && !(RSMP_EXP_SKIP & 64)) {
+      if (!(RSMP_EXP_SKIP & 64)) {
         if (s < kSA ? (whole || n < V) : (tid < kPad && n < V)) smp[n] = make_double2(v[s].x, v[s].y);
       }
-      if (RSMP_EXP_SKIP & 64) continue;
-      if (s == 0 && tid < nm1) {
-        seamA[tid] = v[0].x;
-        seamB[tid] = v[0].y;
-      }
-      if ((s + 1) * T > tail0 && s * T < V) {              // the tail's slot(s)
-        if (n >= tail0 && n < V) {
-          seamA[32 + n - tail0] = v[s].x;
-          seamB[32 + n - tail0] = v[s].y;
-        }
-      }
+    }
+    if (tid < nm1 && !(RSMP_EXP_SKIP & 64)) {
+      seamA[tid] = v[0].x;
+      seamB[tid] = v[0].y;
     }
     if (tid < kPad) { // finite guard values: padded coefficients are zero, 0 * x must stay 0
       smp[tid - kPad] = make_double2(0.0, 0.0);
@@ -255,6 +254,18 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     }
   }
   __syncthreads();
+  // the block's last n-1 samples -> seam ring, read back from whichever LDS image holds them (element 0 of `img` = sample n0)
+  const int tail0 = V - nm1;
+  auto store_tail = [&](const double2 *img, int n0) {
+    if (tid < nm1 && !(RSMP_EXP_SKIP & 64)) {
+      const int slot = (int)(B & a.seam_mask);
+      const double2 t = img[tail0 + tid - n0];
+      a.seam[((long long)(slot * (a.d.C + 1) + ca) * 2 + 1) * 32 + tid] = t.x;
+      a.seam[((long long)(slot * (a.d.C + 1) + cb) * 2 + 1) * 32 + tid] = t.y;
+    }
+  };
+  const bool tail_in_b = tail0 >= kSB0 * T; // uniform: else the whole tail lies inside the first image (V <= kSB0 * T + n - 1)
+  if (!tail_in_b) store_tail(smp, 0);
   RSMP_STAMP(4)
 
   // ---------------------------------------------------------------- polyphase FIR on v_mfma_f64_4x4x4, tile by tile
@@ -437,6 +448,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     if (tid < kPad && V > kSB0 * T) l2[V - kSB0 * T + tid] = make_double2(0.0, 0.0);
   }
   __syncthreads();
+  if (tail_in_b) store_tail(reinterpret_cast<const double2 *>(lds), kSB0 * T);
   if (run && fb.KA < fb.K) poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSB0 * T, kSB0 * T, V + kPad - 4 * KS);
   RSMP_STAMP(5)
 #ifdef RSMP_STAMPS_BUILD
