@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Turn the scratch output of tools/gpu_r2_final.sh (gpurun_out/r2final) into the tracked artefacts under profiles/:
+"""Turn the scratch output of tools/gpu_evidence.sh TAG (gpurun_out/TAG) into the tracked artefacts under profiles/:
 
-  profiles/rNN_cfg{1,2}_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --config K`
+  profiles/rNN_cfgK_kernel_stats.csv       rocprofv3 --kernel-trace --stats summary of `bench.py --config K`, K = 0..4
   profiles/rNN_pmc_summary.json            mean per-dispatch counter values of every rsmp kernel, per PMC pass
   profiles/rNN_bench_lines.jsonl           the bench lines of all BASELINE configs of the same run
   profiles/traffic.json                    HBM bytes per launch, keyed by (config, streams, frames, kernel): what
                                            bench.py's roofline.traffic looks up (FETCH_SIZE KB x 1024 x 2 + WRITE_SIZE KB x 1024,
                                            separate passes, MI355X_MICROARCH.md's gfx950 correction)
 
-usage: tools/collect_profiles.py [gpurun_out/r2final] [r02]"""
+usage: tools/collect_profiles.py gpurun_out/TAG rNN"""
 import collections
 import csv
 import glob
@@ -18,8 +18,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2final")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r3final")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 prof = os.path.join(ROOT, "profiles")
 
 
@@ -29,7 +29,7 @@ def short(name):
 
 
 # kernel stats
-for k in (1, 2):
+for k in (0, 1, 2, 3, 4):
     for f in glob.glob(os.path.join(src, "stats_cfg%d" % k, "*kernel_stats.csv")):
         shutil.copy(f, os.path.join(prof, "%s_cfg%d_kernel_stats.csv" % (tag, k)))
 
@@ -78,7 +78,7 @@ def per_step(pass_summary, counter):
 
 
 records = []
-for k in (1, 2):
+for k in (0, 1, 2, 3, 4):
     if "pmc_cfg%d_fetch" % k not in summary or "pmc_cfg%d_write" % k not in summary:
         continue
     fe, _ = per_step(summary["pmc_cfg%d_fetch" % k], "FETCH_SIZE")
@@ -93,7 +93,7 @@ for k in (1, 2):
         f_kb, w_kb = fe[kern], wr[kern]
         records.append({"config": k, "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_push": cfg["frames_per_push"], "kernel": kern,
                         "fetch_size_kb_raw": f_kb, "write_size_kb": w_kb, "hbm_bytes_per_launch": int(round(f_kb * 1024 * 2 + w_kb * 1024))})
-json.dump({"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_r2_final.sh): "
+json.dump({"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_evidence.sh): "
                        "FETCH_SIZE KB x 1024 x 2 (gfx950 reports half of a streaming read, MI355X_MICROARCH.md) + WRITE_SIZE KB x 1024. "
                        "bench.py looks a workload up by (config, streams, frames, kernel) and prints null when nothing matches. "
                        "Written by tools/collect_profiles.py.",

@@ -11,5 +11,5 @@ timeout -k 10 300 python tools/fuzz_device.py 40 32 > $O/fuzz_device.log 2>&1; e
 cfgs=$1; shift
 for cfg in $cfgs; do
   echo "config $cfg"
-  bash tools/gpu_ab.sh $cfg base "$@"
+  bash tools/gpu_ab_many.sh $cfg 2 base "$@"
 done
