@@ -643,6 +643,7 @@ Engine::~Engine()
   pinned_free(pin_in_[0]);
   pinned_free(pin_in_[1]);
   pinned_free(pin_out_);
+  pinned_free(pin_mir_);
   if (stamps_) {
     unsigned long long h[16] = {};
     if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7] && h[9])
@@ -783,434 +784,519 @@ void Engine::note_input(Book &b, size_t n) const
   }
 }
 
-// One pass of rate_process (rate_base.h:425-432) after `n_new` frames were appended to fifo 0.
-// With launch == false only the counters move (used to size a drain).
+// What the per-stage functions of one pass share (see Engine::Pass): stage i reads fifo i and writes fifo i + 1.
+#define RSMP_STAGE_LOCALS(ps, i)                                                                                   \
+  Book &b = (ps).b;                                                                                                \
+  const bool launch = (ps).launch;                                                                                 \
+  const ExtIn &ein = (ps).ein;                                                                                     \
+  const ExtOut &eout = (ps).eout;                                                                                  \
+  const int ns = int(plan_.stages.size());                                                                         \
+  const StageSpec &sp = plan_.stages[i];                                                                           \
+  Book::St &st = b.st[i];                                                                                          \
+  long long &rd = b.rd[i];                                                                                         \
+  long long &wro = b.wr[(i) + 1];                                                                                  \
+  const long long occ = b.wr[i] - rd;                                                                              \
+  const bool src_f32 = (i) == 0, dst_f32 = (i) + 1 == ns;                                                          \
+  const long long rd_before = rd, wro_before = wro;                                                                \
+  const long long out_offset = (i) + 1 < ns ? plan_.stages[(i) + 1].preload : -b.trimmed;                          \
+  const F32View nof = {};                                                                                          \
+  const F64View nod = {};                                                                                          \
+  Pending &pend = (ps).pend;                                                                                       \
+  /* what the destination ring must be able to hold once this stage has run */                                    \
+  auto dst_need = [&](long long wr_after) {                                                                        \
+    if (dst_f32 && eout.ptr) return std::max<long long>(0, wr_after - std::max(eout.end, b.rd[(i) + 1]));         \
+    return wr_after - b.rd[(i) + 1];                                                                               \
+  };                                                                                                               \
+  (void)rd_before; (void)wro_before; (void)out_offset; (void)occ; (void)src_f32; (void)dst_f32; (void)launch;      \
+  (void)ein; (void)nof; (void)nod; (void)pend; (void)st; (void)dst_need
+
+// One pass of rate_process (rate_base.h:425-432) after `n_new` frames were appended to fifo 0: every stage runs once over
+// what is available.  With launch == false only the counters move (used to size a drain or a host mirror).
 int Engine::advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout, bool more_slabs)
 {
-  const int ns = int(plan_.stages.size());
   note_input(b, n_new);
   b.wr[0] += (long long)n_new;
-  F32View nof = {};
-  F64View nod = {};
-  Pending pend;
-  DftArgs pend_args = {};
-  int pend_log2n = 0, pend_log2p = 0;
+  Pass ps{b, launch, ein, eout, more_slabs, Pending()};
+  for (int i = 0; i < int(plan_.stages.size()); ++i) {
+    const StageKind kind = plan_.stages[i].kind;
+    const int rc = kind == StageKind::Dft ? advance_dft(ps, i) : kind == StageKind::Poly ? advance_poly(ps, i) : advance_half(ps, i);
+    if (rc) return rc;
+  }
+  return kOk;
+}
 
-  for (int i = 0; i < ns; ++i) {
-    const StageSpec &sp = plan_.stages[i];
-    Book::St &st = b.st[i];
-    long long &rd = b.rd[i];
-    long long &wro = b.wr[i + 1];
-    const long long occ = b.wr[i] - rd;
-    const bool src_f32 = i == 0, dst_f32 = i + 1 == ns;
-    const long long rd_before = rd, wro_before = wro;
-    const long long out_offset = i + 1 < ns ? plan_.stages[i + 1].preload : -b.trimmed;
-
-    // what the destination ring must be able to hold once this stage has run
-    auto dst_need = [&](long long wr_after) {
-      if (dst_f32 && eout.ptr) return std::max<long long>(0, wr_after - std::max(eout.end, b.rd[i + 1]));
-      return wr_after - b.rd[i + 1];
-    };
-
-    if (sp.kind == StageKind::Dft) {
-      const DftFilter &f = plan_.dft[sp.filt];
-      const int N = f.N, ov = f.num_taps - 1, V = N - ov, L = sp.L;
-      const bool stuffing = L != 1 && !pow2_ge2(L);
-      const int kept = sp.step < 0 ? N - ((((1 << -sp.step) - 1) * N + ov) >> -sp.step) : V; // dft_filter.h:187
-      long long num_in = std::max<long long>(0, occ);
-      const long long B0 = st.B;
-      int nblocks = 0;
-      while (st.remL + (long long)L * num_in >= N) { // dft_filter.h:78-84
-        const int span = V - st.remL + L - 1;
-        const int take = span / L, rem = span % L;
-        rd += take;
-        num_in -= take;
-        if (stuffing) st.remL = L - 1 - rem;
-        if (sp.step > 1) {
-          const int j = (V - st.remM + sp.step - 1) / sp.step; // dft_filter.h:150-152
-          st.remM = st.remM + j * sp.step - V;
-          wro += j;
-        } else
-          wro += kept;
-        ++nblocks;
-        ++st.B;
-      }
-      const bool fused = fuse_[i].on;
-      if (launch && nblocks) {
-        if (!fused) {
-          int rc = ensure_ring(i + 1, dst_need(wro));
-          if (rc) return rc;
-        }
-        const int Ng = N, Vg = V;
-        const int log2n = ilog2(Ng);
-        DftArgs a;
-        a.G = d_G_[sp.filt];
-        a.Gr = d_Gr_[sp.filt];
-        const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
-        const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
-        const bool big = big_[i].on;
-        a.tw_fwd = twiddles(big ? log2p - 4 : log2p);
-        a.tw_inv = twiddles(big ? log2nd - 4 : log2nd);
-        a.tw_fwd8 = (!big && log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
-        if (!big && log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
-        a.tw_inv8 = (!big && log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
-        if (!big && log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
-        a.B0 = B0;
-        a.out_offset = out_offset;
-        a.nblocks = nblocks;
-        a.C = C_;
-        a.L = L;
-        a.c0 = pow2_ge2(L) ? 0 : sp.remL0; // the frequency-domain branch places input 0 of a block at slot 0 whatever remL is
-        a.V = Vg;
-        a.Vout = sp.step < 0 ? Ng - ((((1 << -sp.step) - 1) * Ng + ov) >> -sp.step) : Vg;
-        a.q = (Vg - sp.remL0 + L - 1) / L;
-        a.M = sp.step > 1 ? sp.step : 1;
-        a.hp = 0; // set by the launchers (frame_pairs)
-        a.nchs = pair_nchs();
-        a.in_limit = 0x7fffffffffffffffLL;
-        a.clip_lo = -0x7fffffffffffffffLL;
-        a.clip_hi = 0x7fffffffffffffffLL;
-        if (big) {
-          const BigDft &bg = big_[i];
-          BigDftArgs ba;
-          ba.d = a;
-          ba.twN = bg.twN;
-          ba.w1 = bg.w1;
-          ba.w2 = bg.w2;
-          ba.log2n = log2n;
-          ba.log2mp = log2p - 4;
-          ba.log2md = log2nd - 4;
-          ba.fdomain_in = (log2p < log2n || L == 1) ? 1 : 0;
-          ba.item0 = 0;
-          const int pi = prof_begin(true, "rsmp::big_cols_fwd_kernel + big_rows_kernel + big_cols_inv_kernel");
-          HIP_TRY(launch_dft_big(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                                 dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), ba, bg.ws_items,
-                                 stream_));
-          prof_end(pi);
-        } else
-        if (fused) { // launched together with the polyphase stage below
-          pend.B0 = B0;
-          pend.nblocks = nblocks;
-          pend_args = a;
-          pend_log2n = log2n;
-          pend_log2p = log2p;
-        } else if (a.Gr && sp.step == 1 && fdomain_up(L) && dftx_supported(log2n, log2p, log2nd)) {
-          const int pi = prof_begin(true);
-          const char *kn = nullptr;
-          HIP_TRY(launch_dftx(log2n, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                              dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
-          prof_name(pi, kn);
-          prof_end(pi);
-        } else {
-        const int pi = prof_begin(true);
-        const char *kn = nullptr;
-        HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
-                           src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                           dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
-        prof_name(pi, kn);
-        prof_end(pi);
-        }
-      }
-    } else if (sp.kind == StageKind::Poly) {
-      const long long num_in = std::max<long long>(0, occ - sp.pre_post); // rate_base.h:130
-      long long count = 0, at_end = st.at;
-      const long long step = sp.order == 0 ? (sp.step64 >> 32) : sp.step64;
-      const long long lim = sp.order == 0 ? num_in * sp.L : (num_in << 32);
-      if (st.at < lim) count = (lim - st.at + step - 1) / step; // rate_filters_generic.h:281 / :477
-      at_end = st.at + count * step;
-      const bool fused = i > 0 && fuse_[i - 1].on;
-      if (launch && fused) {
-        if ((count != 0) != (pend.nblocks != 0)) return kInternal;
-        if (pend.nblocks) {
-          int rc = ensure_ring(i + 1, dst_need(wro + count));
-          if (rc) return rc;
-          const Fuse &fu = fuse_[i - 1];
-          FusedArgs fa;
-          fa.d = pend_args;
-          fa.tab = d_poly_;
-          fa.seam = fu.seam;
-          fa.cft = fu.cft;
-          fa.at0 = sp.at0 >> 32;
-          fa.b_offset = sp.preload;
-          fa.out_offset2 = out_offset;
-          fa.seam_mask = fu.slots - 1;
-          fa.n = sp.n;
-          fa.polyL = sp.L;
-          fa.step = int(step);
-          fa.span = fu.span;
-          fa.NG = fu.NG;
-          fa.KC = fu.KC;
-          fa.kper = fu.kper;
-          fa.cfm = fu.cfm;
-          fa.qtab = fu.qtab;
-          fa.cfm2 = fu.cfm2;
-          fa.NGRP = fu.NGRP;
-          fa.KS = fu.KS;
-          fa.dbg = dbg_;
-          fa.stamps = stamps_;
-          if (pend.nblocks > fu.blk_cap) return kInternal;
-          FusedPrepArgs pa; // output bookkeeping of each block (closed forms in kernels.hpp), evaluated on the device
-          pa.b_offset = fa.b_offset;
-          pa.B0 = pend.B0;
-          pa.at0 = fa.at0;
-          pa.V = fa.d.V;
-          pa.polyL = sp.L;
-          pa.step = int(step);
-          pa.n = sp.n;
-          pa.nblocks = pend.nblocks;
-          pa.two_round = fu.cfm != nullptr;
-          pa.KS = fu.KS;
-          pa.qb_max = fu.qb_max;
-          pa.qb_min = fu.qb_min;
-          pa.clip_lo = 0;
-          pa.clip_hi = 0x7fffffffffffffffLL;
-          for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
-            if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
-          // side stream for the seam kernel only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
-          // ... and only when another slab of this push follows: seam(k) then runs beside fused(k+1).  Behind the LAST fused
-          // launch of a push the side stream has nothing to overlap with but the small carry copy, and the two cross-queue
-          // hand-overs (event -> side stream -> join) cost more than they hide: 2.455 against 2.505 ms per step measured.
-          const bool seam_on_side = more_slabs && !(profiling_ || !dst_f32 || no_side_);
-          // seam(k-2), possibly still pending on the side stream, reads the seam-ring slots AND the half of the block table
-          // that this launch is about to overwrite: both the table fill and the fused launch wait for it.  (The table has
-          // two halves, launch k uses half k & 1: seam(k-1) may still be reading the other one.  With ONE table, a push cut
-          // into three launches lost the seam outputs of its first blocks: tests/test_gpu_round3.py::test_cfg0_bench_shape_*.)
-          if (seam_launches_ >= 2) HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
-          FusedBlock *const blk_half = fu.blk_dev + size_t(seam_launches_ & 1) * fu.blk_cap;
-          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, blk_half, stream_)); prof_end(pp); }
-          fa.blk = blk_half;
-          // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
-          const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
-          if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
-          const bool s32 = i - 1 == 0;
-          // Blocks whose input span and outputs lie in the caller's buffers as plain interleaved frames go to the lean
-          // kernel (fused_fast.hip); the others (the block that straddles ring and buffer, ring wrap, odd channel counts,
-          // fp64 rings on either side) to the generic one.  At most three launches: generic head, lean middle, generic tail.
-          int f0 = 0, f1 = 0;
-          FastIo io = {};
-          if (fu.cfm && s32 && dst_f32 && !(nch_ & 1) && ein.ptr && eout.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
-              !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7) && !(ein.stride_floats & 1) &&
-              !(eout.stride_floats & 1)) {
-            const long long P = 1LL << pend_log2p, q = fa.d.q;
-            // (a block that starts below the caller's buffer takes its head from fifo 0's ring: the lean kernel handles that too)
-            const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
-            f0 = 0;
-            f1 = int(std::min<long long>(pend.nblocks, hi));
-            // outputs of blocks [f0, f1) must lie inside the caller's output buffer
-            while (f0 < f1) {
-              const FusedBlock b0 = fused_block_info(pa, f0), b1 = fused_block_info(pa, f1 - 1);
-              if (out_offset + b0.i_lo < eout.begin) { ++f0; continue; }
-              if (out_offset + b1.i_lo + b1.cnt > eout.end) { --f1; continue; }
-              break;
-            }
-            if (f0 >= f1) f0 = f1 = 0;
-            io.in = ein.ptr;
-            io.in_ring = static_cast<const float *>(rings_[0].buf);
-            io.in_ring_mask = rings_[0].cap - 1;
-            io.in_ring_stream_stride = rings_[0].cap * nch_;
-            io.out = eout.ptr;
-            io.in_abs0 = ein.begin;
-            io.out_abs0 = eout.begin;
-            io.in_stream_stride = ein.stride_floats;
-            io.out_stream_stride = eout.stride_floats;
-            io.nch = nch_;
-          } else if (fu.cfm && s32 && !dst_f32 && !(nch_ & 1) && ein.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
-                     !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(ein.stride_floats & 1)) {
-            // the polyphase stage feeds another stage: same lean kernel, its outputs into the next fifo's fp64 ring (any ring
-            // position: the kernel masks the index), so only the input side limits the range
-            const long long P = 1LL << pend_log2p, q = fa.d.q;
-            const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
-            f0 = 0;
-            f1 = int(std::max<long long>(0, std::min<long long>(pend.nblocks, hi)));
-            io.in = ein.ptr;
-            io.in_ring = static_cast<const float *>(rings_[0].buf);
-            io.in_ring_mask = rings_[0].cap - 1;
-            io.in_ring_stream_stride = rings_[0].cap * nch_;
-            io.in_abs0 = ein.begin;
-            io.in_stream_stride = ein.stride_floats;
-            io.nch = nch_;
-            io.out64 = static_cast<double *>(rings_[i + 1].buf);
-            io.out64_mask = rings_[i + 1].cap - 1;
-            io.out64_chan_stride = rings_[i + 1].cap;
-          }
-          auto launch_range = [&](int b0, int b1, bool fast) -> int {
-            if (b0 >= b1) return kOk;
-            FusedArgs fr = fa;
-            fr.d.B0 = fa.d.B0 + b0;
-            fr.d.nblocks = b1 - b0;
-            fr.blk = fa.blk + b0;
-            const int pi = prof_begin(true);
-            const char *kn = nullptr;
-            if (fast) HIP_TRY(launch_fused_fast(pend_log2p, fr, io, stream_, &kn));
-            else
-              HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
-                                   s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                                   dst_f32 ? nod : f64_view(i + 1), fr, stream_, &kn));
-            prof_name(pi, kn);
-            prof_end(pi);
-            return kOk;
-          };
-          { int rl = launch_range(0, f0, false); if (rl) return rl; }
-          { int rl = launch_range(f0, f1, true); if (rl) return rl; }
-          { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
-          if (!seam_on_side) {
-            { int rcj = join_side(); if (rcj) return rcj; } // (a seam kernel of an earlier launch of this push may still be on the side stream)
-            const int ps = prof_begin(false, "rsmp::seam_kernel");
-            HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
-            prof_end(ps);
-          } else {
-            HIP_TRY(hipEventRecord(ev_fused_, stream_));
-            HIP_TRY(hipStreamWaitEvent(side_, ev_fused_, 0));
-            HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, side_));
-            HIP_TRY(hipEventRecord(ev_seam_[seam_launches_ & 1], side_));
-            ++seam_launches_;
-            side_pending_ = true;
-          }
-        }
-      } else if (launch && count && polymf_[i].cfm) {
-        int rc = ensure_ring(i + 1, dst_need(wro + count));
-        if (rc) return rc;
-        const PolyMf &pm = polymf_[i];
-        const long long at0 = sp.at0 >> 32, i_begin = wro_before - out_offset, i_end = i_begin + count;
-        const long long q_first = (at0 + i_begin * step) / sp.L, q_last = (at0 + (i_end - 1) * step) / sp.L;
-        for (long long t0 = q_first / pm.Vt, t_end = q_last / pm.Vt + 1; t0 < t_end; t0 += pm.blk_cap) {
-          FusedPrepArgs pa; // per-tile bookkeeping: the closed forms of the fused path with V = Vt, no seam exclusion
-          pa.b_offset = 0;
-          pa.B0 = t0;
-          pa.at0 = at0;
-          pa.V = pm.Vt;
-          pa.polyL = sp.L;
-          pa.step = int(step);
-          pa.n = 1;
-          pa.nblocks = int(std::min<long long>(pm.blk_cap, t_end - t0));
-          pa.two_round = 0;
-          pa.KS = pm.KS;
-          pa.qb_max = 0;
-          pa.qb_min = 0;
-          pa.clip_lo = i_begin;
-          pa.clip_hi = i_end;
-          for (int k : {0, pa.nblocks - 1})
-            if (fused_block_info(pa, k).K > 32) return kInternal; // 4 column steps x 2 halves x 4 periods
-          { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, pm.blk, stream_)); prof_end(pp); }
-          PolyMfArgs a;
-          a.cfm = pm.cfm;
-          a.qtab = pm.qtab;
-          a.blk = pm.blk;
-          a.B0 = t0;
-          a.at0 = at0;
-          a.out_offset = out_offset;
-          a.in_limit = b.wr[i];
-          a.nblocks = pa.nblocks;
-          a.C = C_;
-          a.Vt = pm.Vt;
-          a.n = sp.n;
-          a.polyL = sp.L;
-          a.step = int(step);
-          a.NGRP = pm.NGRP;
-          a.nchs = pair_nchs();
-          const int pi = prof_begin(false);
-          const char *kn = nullptr;
-          HIP_TRY(launch_polymf(pm.KS, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                                dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
-          prof_name(pi, kn);
-          prof_end(pi);
-        }
-      } else if (launch && count) {
-        int rc = ensure_ring(i + 1, dst_need(wro + count));
-        if (rc) return rc;
-        PolyArgs a;
-        a.tab = d_poly_;
-        a.rd = rd_before;
-        a.at = st.at;
-        a.step = step;
-        a.out_abs = wro_before;
-        a.count = count;
-        a.C = C_;
-        a.n = sp.n;
-        a.L = sp.L;
-        a.phase_bits = sp.phase_bits;
-        const double in_per_out = sp.order == 0 ? double(step) / sp.L : double(step) / 4294967296.0;
-        // LDS: window of the tile, plus (rational stages) the whole coefficient table when both fit 64 KB;
-        // the kernel's 32-bit clock needs tile * step < 2^31
-        const size_t tab_bytes = sp.order == 0 ? size_t(sp.L) * sp.n * 8 : 0;
-        const bool tab_lds = sp.order == 0 && tab_bytes <= 40 * 1024;
-        const double lds_for_window = tab_lds ? double(64 * 1024 - 16) - double(tab_bytes) : 48.0 * 1024;
-        int tile = 2048;
-        while (tile > 256 && ((tile * in_per_out + sp.n + 4) * 8 > lds_for_window ||
-                              (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0)))
-          tile >>= 1;
-        if (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0) return kInternal;
-        a.tile = tile;
-        a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
-        a.tab_lds = tab_lds;
-        a.coop = sp.order >= 1 && sp.n % 8 == 0 && !knobs().no_polycoop;
-        a.shared_rows = 0;
-        if (sp.order >= 1 && sp.n <= 32 && !knobs().no_polyi) { // (polyi_kernel maps 32 lanes along a coefficient row: n <= 32) // the channels of a handle share the clock: share the interpolated rows
-          const double wl = 128 * in_per_out + sp.n + 4; // window of a 128-output tile (kPolyiTile)
-          if ((128.0 * sp.n + 16.0 * (wl + 1)) * 8 <= 150.0 * 1024) { // rows + 16 channel windows must fit LDS
-            a.shared_rows = 1;
-            a.tile = 128;
-            a.win = int(wl) | 1;
-          }
-        }
-        const int pi = prof_begin(false);
-        const char *kn = nullptr;
-        HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
-                            src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
-                            dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
-        prof_name(pi, kn);
-        prof_end(pi);
-      }
-      if (sp.order == 0) {
-        rd += at_end / sp.L; // rate_filters_generic.h:302-304
-        st.at = at_end % sp.L;
-      } else {
-        rd += at_end >> 32; // rate_filters_generic.h:499-500
-        st.at = at_end & 0xffffffffLL;
-      }
-      wro += count;
+// dft_stage_fn (dft_filter.h:60-190): the reference's block loop on the counters, then one launch for all blocks of the pass
+int Engine::advance_dft(Pass &ps, int i)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  DftArgs &pend_args = pend.args;
+  int &pend_log2n = pend.log2n, &pend_log2p = pend.log2p;
+  const DftFilter &f = plan_.dft[sp.filt];
+  const int N = f.N, ov = f.num_taps - 1, V = N - ov, L = sp.L;
+  const bool stuffing = L != 1 && !pow2_ge2(L);
+  const int kept = sp.step < 0 ? N - ((((1 << -sp.step) - 1) * N + ov) >> -sp.step) : V; // dft_filter.h:187
+  long long num_in = std::max<long long>(0, occ);
+  const long long B0 = st.B;
+  int nblocks = 0;
+  while (st.remL + (long long)L * num_in >= N) { // dft_filter.h:78-84
+    const int span = V - st.remL + L - 1;
+    const int take = span / L, rem = span % L;
+    rd += take;
+    num_in -= take;
+    if (stuffing) st.remL = L - 1 - rem;
+    if (sp.step > 1) {
+      const int j = (V - st.remM + sp.step - 1) / sp.step; // dft_filter.h:150-152
+      st.remM = st.remM + j * sp.step - V;
+      wro += j;
+    } else
+      wro += kept;
+    ++nblocks;
+    ++st.B;
+  }
+  const bool fused = fuse_[i].on;
+  if (launch && nblocks) {
+    if (!fused) {
+      int rc = ensure_ring(i + 1, dst_need(wro));
+      if (rc) return rc;
+    }
+    const int Ng = N, Vg = V;
+    const int log2n = ilog2(Ng);
+    DftArgs a;
+    a.G = d_G_[sp.filt];
+    a.Gr = d_Gr_[sp.filt];
+    const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
+    const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
+    const bool big = big_[i].on;
+    a.tw_fwd = twiddles(big ? log2p - 4 : log2p);
+    a.tw_inv = twiddles(big ? log2nd - 4 : log2nd);
+    a.tw_fwd8 = (!big && log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
+    if (!big && log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
+    a.tw_inv8 = (!big && log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
+    if (!big && log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
+    a.B0 = B0;
+    a.out_offset = out_offset;
+    a.nblocks = nblocks;
+    a.C = C_;
+    a.L = L;
+    a.c0 = pow2_ge2(L) ? 0 : sp.remL0; // the frequency-domain branch places input 0 of a block at slot 0 whatever remL is
+    a.V = Vg;
+    a.Vout = sp.step < 0 ? Ng - ((((1 << -sp.step) - 1) * Ng + ov) >> -sp.step) : Vg;
+    a.q = (Vg - sp.remL0 + L - 1) / L;
+    a.M = sp.step > 1 ? sp.step : 1;
+    a.hp = 0; // set by the launchers (frame_pairs)
+    a.nchs = pair_nchs();
+    a.in_limit = 0x7fffffffffffffffLL;
+    a.clip_lo = -0x7fffffffffffffffLL;
+    a.clip_hi = 0x7fffffffffffffffLL;
+    if (big) {
+      const BigDft &bg = big_[i];
+      BigDftArgs ba;
+      ba.d = a;
+      ba.twN = bg.twN;
+      ba.w1 = bg.w1;
+      ba.w2 = bg.w2;
+      ba.log2n = log2n;
+      ba.log2mp = log2p - 4;
+      ba.log2md = log2nd - 4;
+      ba.fdomain_in = (log2p < log2n || L == 1) ? 1 : 0;
+      ba.item0 = 0;
+      const int pi = prof_begin(true, "rsmp::big_cols_fwd_kernel + big_rows_kernel + big_cols_inv_kernel");
+      HIP_TRY(launch_dft_big(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                             dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), ba, bg.ws_items,
+                             stream_));
+      prof_end(pi);
+    } else
+    if (fused) { // launched together with the polyphase stage below
+      pend.B0 = B0;
+      pend.nblocks = nblocks;
+      pend_args = a;
+      pend_log2n = log2n;
+      pend_log2p = log2p;
+    } else if (a.Gr && sp.step == 1 && fdomain_up(L) && dftx_supported(log2n, log2p, log2nd)) {
+      const int pi = prof_begin(true);
+      const char *kn = nullptr;
+      HIP_TRY(launch_dftx(log2n, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                          dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+      prof_name(pi, kn);
+      prof_end(pi);
     } else {
-      const long long avail = std::max<long long>(0, occ - sp.pre_post);
-      const long long num_out = (avail + 1) / 2; // rate_filters_generic.h:83
-      if (launch && num_out) {
-        int rc = ensure_ring(i + 1, dst_need(wro + num_out));
-        if (rc) return rc;
-        HalfArgs a;
-        a.rd = rd_before;
-        a.out_abs = wro_before;
-        a.count = num_out;
-        a.C = C_;
-        a.ncoef = sp.hb_n;
-        a.pre = sp.pre;
-        for (int k = 0; k < 13; ++k) a.coef[k] = k < sp.hb_n ? sp.hb[k] : 0.0;
-        const int pi = prof_begin(false);
-        const char *kn = nullptr;
-        HIP_TRY(launch_half(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
-                            dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
-        prof_name(pi, kn);
-        prof_end(pi);
-      }
-      if (2 * num_out <= occ) rd += 2 * num_out; // fifo_read refuses to over-read, fifo.h:169
-      wro += num_out;
+    const int pi = prof_begin(true);
+    const char *kn = nullptr;
+    HIP_TRY(launch_dft(log2n, log2p, log2nd, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
+                       src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                       dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+    prof_name(pi, kn);
+    prof_end(pi);
     }
   }
   return kOk;
 }
 
+// vpoly0..3 (rate_filters_generic.h:272-305, 376-504): output count from the clock, then the launch of whichever kernel serves
+// this stage (fused with the dft stage in front of it, matrix-pipe stage of its own, or the generic polyphase kernels)
+int Engine::advance_poly(Pass &ps, int i)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  const long long num_in = std::max<long long>(0, occ - sp.pre_post); // rate_base.h:130
+  long long count = 0, at_end = st.at;
+  const long long step = sp.order == 0 ? (sp.step64 >> 32) : sp.step64;
+  const long long lim = sp.order == 0 ? num_in * sp.L : (num_in << 32);
+  if (st.at < lim) count = (lim - st.at + step - 1) / step; // rate_filters_generic.h:281 / :477
+  at_end = st.at + count * step;
+  const bool fused = i > 0 && fuse_[i - 1].on;
+  if (launch && fused) {
+    if ((count != 0) != (pend.nblocks != 0)) return kInternal;
+    if (pend.nblocks) {
+      const int rc = launch_fused_pair(ps, i, count, step);
+      if (rc) return rc;
+    }
+  } else if (launch && count && polymf_[i].cfm) {
+    const int rc = launch_polymf_stage(ps, i, count, step);
+    if (rc) return rc;
+  } else if (launch && count) {
+    const int rc = launch_poly_stage(ps, i, count, step);
+    if (rc) return rc;
+  }
+  if (sp.order == 0) {
+    rd += at_end / sp.L; // rate_filters_generic.h:302-304
+    st.at = at_end % sp.L;
+  } else {
+    rd += at_end >> 32; // rate_filters_generic.h:499-500
+    st.at = at_end & 0xffffffffLL;
+  }
+  wro += count;
+  return kOk;
+}
+
+// the dft stage i - 1 and this rational polyphase stage as ONE kernel per block range (fused_fast.hip / fused.hip) + seam_kernel
+int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  const bool more_slabs = ps.more_slabs;
+  DftArgs &pend_args = pend.args;
+  const int pend_log2n = pend.log2n, pend_log2p = pend.log2p;
+  {
+    int rc = ensure_ring(i + 1, dst_need(wro + count));
+    if (rc) return rc;
+    const Fuse &fu = fuse_[i - 1];
+    FusedArgs fa;
+    fa.d = pend_args;
+    fa.tab = d_poly_;
+    fa.seam = fu.seam;
+    fa.cft = fu.cft;
+    fa.at0 = sp.at0 >> 32;
+    fa.b_offset = sp.preload;
+    fa.out_offset2 = out_offset;
+    fa.seam_mask = fu.slots - 1;
+    fa.n = sp.n;
+    fa.polyL = sp.L;
+    fa.step = int(step);
+    fa.span = fu.span;
+    fa.NG = fu.NG;
+    fa.KC = fu.KC;
+    fa.kper = fu.kper;
+    fa.cfm = fu.cfm;
+    fa.qtab = fu.qtab;
+    fa.cfm2 = fu.cfm2;
+    fa.NGRP = fu.NGRP;
+    fa.KS = fu.KS;
+    fa.dbg = dbg_;
+    fa.stamps = stamps_;
+    if (pend.nblocks > fu.blk_cap) return kInternal;
+    FusedPrepArgs pa; // output bookkeeping of each block (closed forms in kernels.hpp), evaluated on the device
+    pa.b_offset = fa.b_offset;
+    pa.B0 = pend.B0;
+    pa.at0 = fa.at0;
+    pa.V = fa.d.V;
+    pa.polyL = sp.L;
+    pa.step = int(step);
+    pa.n = sp.n;
+    pa.nblocks = pend.nblocks;
+    pa.two_round = fu.cfm != nullptr;
+    pa.KS = fu.KS;
+    pa.qb_max = fu.qb_max;
+    pa.qb_min = fu.qb_min;
+    pa.clip_lo = 0;
+    pa.clip_hi = 0x7fffffffffffffffLL;
+    for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
+      if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
+    // side stream for the seam kernel only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
+    // ... and only when another slab of this push follows: seam(k) then runs beside fused(k+1).  Behind the LAST fused
+    // launch of a push the side stream has nothing to overlap with but the small carry copy, and the two cross-queue
+    // hand-overs (event -> side stream -> join) cost more than they hide: 2.455 against 2.505 ms per step measured.
+    const bool seam_on_side = more_slabs && !(profiling_ || !dst_f32 || no_side_);
+    // seam(k-2), possibly still pending on the side stream, reads the seam-ring slots AND the half of the block table
+    // that this launch is about to overwrite: both the table fill and the fused launch wait for it.  (The table has
+    // two halves, launch k uses half k & 1: seam(k-1) may still be reading the other one.  With ONE table, a push cut
+    // into three launches lost the seam outputs of its first blocks: tests/test_gpu_round3.py::test_cfg0_bench_shape_*.)
+    if (seam_launches_ >= 2) HIP_TRY(hipStreamWaitEvent(stream_, ev_seam_[seam_launches_ & 1], 0));
+    FusedBlock *const blk_half = fu.blk_dev + size_t(seam_launches_ & 1) * fu.blk_cap;
+    { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, blk_half, stream_)); prof_end(pp); }
+    fa.blk = blk_half;
+    // the fused launch emits exactly the outputs [wro, wro + count): windows ending before wr of fifo i
+    const long long endnum = (b.wr[i] - sp.n + 1) * sp.L - fa.at0;
+    if (wro - out_offset + count != (endnum <= 0 ? 0 : (endnum + step - 1) / step)) return kInternal;
+    const bool s32 = i - 1 == 0;
+    // Blocks whose input span and outputs lie in the caller's buffers as plain interleaved frames go to the lean
+    // kernel (fused_fast.hip); the others (the block that straddles ring and buffer, ring wrap, odd channel counts,
+    // fp64 rings on either side) to the generic one.  At most three launches: generic head, lean middle, generic tail.
+    int f0 = 0, f1 = 0;
+    FastIo io = {};
+    if (fu.cfm && s32 && dst_f32 && !(nch_ & 1) && ein.ptr && eout.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
+        !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7) && !(ein.stride_floats & 1) &&
+        !(eout.stride_floats & 1)) {
+      const long long P = 1LL << pend_log2p, q = fa.d.q;
+      // (a block that starts below the caller's buffer takes its head from fifo 0's ring: the lean kernel handles that too)
+      const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
+      f0 = 0;
+      f1 = int(std::min<long long>(pend.nblocks, hi));
+      // outputs of blocks [f0, f1) must lie inside the caller's output buffer
+      while (f0 < f1) {
+        const FusedBlock b0 = fused_block_info(pa, f0), b1 = fused_block_info(pa, f1 - 1);
+        if (out_offset + b0.i_lo < eout.begin) { ++f0; continue; }
+        if (out_offset + b1.i_lo + b1.cnt > eout.end) { --f1; continue; }
+        break;
+      }
+      if (f0 >= f1) f0 = f1 = 0;
+      io.in = ein.ptr;
+      io.in_ring = static_cast<const float *>(rings_[0].buf);
+      io.in_ring_mask = rings_[0].cap - 1;
+      io.in_ring_stream_stride = rings_[0].cap * nch_;
+      io.out = eout.ptr;
+      io.in_abs0 = ein.begin;
+      io.out_abs0 = eout.begin;
+      io.in_stream_stride = ein.stride_floats;
+      io.out_stream_stride = eout.stride_floats;
+      io.nch = nch_;
+    } else if (fu.cfm && s32 && !dst_f32 && !(nch_ & 1) && ein.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
+               !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(ein.stride_floats & 1)) {
+      // the polyphase stage feeds another stage: same lean kernel, its outputs into the next fifo's fp64 ring (any ring
+      // position: the kernel masks the index), so only the input side limits the range
+      const long long P = 1LL << pend_log2p, q = fa.d.q;
+      const long long hi = (ein.end - P) >= 0 ? (ein.end - P) / q - pend.B0 + 1 : 0;
+      f0 = 0;
+      f1 = int(std::max<long long>(0, std::min<long long>(pend.nblocks, hi)));
+      io.in = ein.ptr;
+      io.in_ring = static_cast<const float *>(rings_[0].buf);
+      io.in_ring_mask = rings_[0].cap - 1;
+      io.in_ring_stream_stride = rings_[0].cap * nch_;
+      io.in_abs0 = ein.begin;
+      io.in_stream_stride = ein.stride_floats;
+      io.nch = nch_;
+      io.out64 = static_cast<double *>(rings_[i + 1].buf);
+      io.out64_mask = rings_[i + 1].cap - 1;
+      io.out64_chan_stride = rings_[i + 1].cap;
+    }
+    auto launch_range = [&](int b0, int b1, bool fast) -> int {
+      if (b0 >= b1) return kOk;
+      FusedArgs fr = fa;
+      fr.d.B0 = fa.d.B0 + b0;
+      fr.d.nblocks = b1 - b0;
+      fr.blk = fa.blk + b0;
+      const int pi = prof_begin(true);
+      const char *kn = nullptr;
+      if (fast) HIP_TRY(launch_fused_fast(pend_log2p, fr, io, stream_, &kn));
+      else
+        HIP_TRY(launch_fused(pend_log2n, pend_log2p, s32, dst_f32, s32 ? f32_view(0, &ein, nullptr) : nof,
+                             s32 ? nod : f64_view(i - 1), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                             dst_f32 ? nod : f64_view(i + 1), fr, stream_, &kn));
+      prof_name(pi, kn);
+      prof_end(pi);
+      return kOk;
+    };
+    { int rl = launch_range(0, f0, false); if (rl) return rl; }
+    { int rl = launch_range(f0, f1, true); if (rl) return rl; }
+    { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
+    if (!seam_on_side) {
+      { int rcj = join_side(); if (rcj) return rcj; } // (a seam kernel of an earlier launch of this push may still be on the side stream)
+      const int ps = prof_begin(false, "rsmp::seam_kernel");
+      HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, stream_));
+      prof_end(ps);
+    } else {
+      HIP_TRY(hipEventRecord(ev_fused_, stream_));
+      HIP_TRY(hipStreamWaitEvent(side_, ev_fused_, 0));
+      HIP_TRY(launch_seam(dst_f32, dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), fa, side_));
+      HIP_TRY(hipEventRecord(ev_seam_[seam_launches_ & 1], side_));
+      ++seam_launches_;
+      side_pending_ = true;
+    }
+  }
+  return kOk;
+}
+
+// rational polyphase stage on the matrix pipe as a stage of its own (polymf.hip)
+int Engine::launch_polymf_stage(Pass &ps, int i, long long count, long long step)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  int rc = ensure_ring(i + 1, dst_need(wro + count));
+  if (rc) return rc;
+  const PolyMf &pm = polymf_[i];
+  const long long at0 = sp.at0 >> 32, i_begin = wro_before - out_offset, i_end = i_begin + count;
+  const long long q_first = (at0 + i_begin * step) / sp.L, q_last = (at0 + (i_end - 1) * step) / sp.L;
+  for (long long t0 = q_first / pm.Vt, t_end = q_last / pm.Vt + 1; t0 < t_end; t0 += pm.blk_cap) {
+    FusedPrepArgs pa; // per-tile bookkeeping: the closed forms of the fused path with V = Vt, no seam exclusion
+    pa.b_offset = 0;
+    pa.B0 = t0;
+    pa.at0 = at0;
+    pa.V = pm.Vt;
+    pa.polyL = sp.L;
+    pa.step = int(step);
+    pa.n = 1;
+    pa.nblocks = int(std::min<long long>(pm.blk_cap, t_end - t0));
+    pa.two_round = 0;
+    pa.KS = pm.KS;
+    pa.qb_max = 0;
+    pa.qb_min = 0;
+    pa.clip_lo = i_begin;
+    pa.clip_hi = i_end;
+    for (int k : {0, pa.nblocks - 1})
+      if (fused_block_info(pa, k).K > 32) return kInternal; // 4 column steps x 2 halves x 4 periods
+    { const int pp = prof_begin(false, "rsmp::fused_prep_kernel"); HIP_TRY(launch_fused_prep(pa, pm.blk, stream_)); prof_end(pp); }
+    PolyMfArgs a;
+    a.cfm = pm.cfm;
+    a.qtab = pm.qtab;
+    a.blk = pm.blk;
+    a.B0 = t0;
+    a.at0 = at0;
+    a.out_offset = out_offset;
+    a.in_limit = b.wr[i];
+    a.nblocks = pa.nblocks;
+    a.C = C_;
+    a.Vt = pm.Vt;
+    a.n = sp.n;
+    a.polyL = sp.L;
+    a.step = int(step);
+    a.NGRP = pm.NGRP;
+    a.nchs = pair_nchs();
+    const int pi = prof_begin(false);
+    const char *kn = nullptr;
+    HIP_TRY(launch_polymf(pm.KS, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                          dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+    prof_name(pi, kn);
+    prof_end(pi);
+  }
+  return kOk;
+}
+
+// the generic polyphase kernels: poly_kernel<order>, poly_coop_kernel, polyi_kernel (kernels.hip)
+int Engine::launch_poly_stage(Pass &ps, int i, long long count, long long step)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  int rc = ensure_ring(i + 1, dst_need(wro + count));
+  if (rc) return rc;
+  PolyArgs a;
+  a.tab = d_poly_;
+  a.rd = rd_before;
+  a.at = st.at;
+  a.step = step;
+  a.out_abs = wro_before;
+  a.count = count;
+  a.C = C_;
+  a.n = sp.n;
+  a.L = sp.L;
+  a.phase_bits = sp.phase_bits;
+  const double in_per_out = sp.order == 0 ? double(step) / sp.L : double(step) / 4294967296.0;
+  // LDS: window of the tile, plus (rational stages) the whole coefficient table when both fit 64 KB;
+  // the kernel's 32-bit clock needs tile * step < 2^31
+  const size_t tab_bytes = sp.order == 0 ? size_t(sp.L) * sp.n * 8 : 0;
+  const bool tab_lds = sp.order == 0 && tab_bytes <= 40 * 1024;
+  const double lds_for_window = tab_lds ? double(64 * 1024 - 16) - double(tab_bytes) : 48.0 * 1024;
+  int tile = 2048;
+  while (tile > 256 && ((tile * in_per_out + sp.n + 4) * 8 > lds_for_window ||
+                        (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0)))
+    tile >>= 1;
+  if (sp.order == 0 && double(tile + 256) * double(step) >= 2147483648.0) return kInternal;
+  a.tile = tile;
+  a.win = (int(tile * in_per_out) + sp.n + 4 + 1) & ~1;
+  a.tab_lds = tab_lds;
+  a.coop = sp.order >= 1 && sp.n % 8 == 0 && !knobs().no_polycoop;
+  a.shared_rows = 0;
+  if (sp.order >= 1 && sp.n <= 32 && !knobs().no_polyi) { // (polyi_kernel maps 32 lanes along a coefficient row: n <= 32) // the channels of a handle share the clock: share the interpolated rows
+    const double wl = 128 * in_per_out + sp.n + 4; // window of a 128-output tile (kPolyiTile)
+    if ((128.0 * sp.n + 16.0 * (wl + 1)) * 8 <= 150.0 * 1024) { // rows + 16 channel windows must fit LDS
+      a.shared_rows = 1;
+      a.tile = 128;
+      a.win = int(wl) | 1;
+    }
+  }
+  const int pi = prof_begin(false);
+  const char *kn = nullptr;
+  HIP_TRY(launch_poly(sp.order, src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof,
+                      src_f32 ? nod : f64_view(i), dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof,
+                      dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+  prof_name(pi, kn);
+  prof_end(pi);
+  return kOk;
+}
+
+// h8..h13 (rate_filters_generic.h:31-262)
+int Engine::advance_half(Pass &ps, int i)
+{
+  RSMP_STAGE_LOCALS(ps, i);
+  const long long avail = std::max<long long>(0, occ - sp.pre_post);
+  const long long num_out = (avail + 1) / 2; // rate_filters_generic.h:83
+  if (launch && num_out) {
+    int rc = ensure_ring(i + 1, dst_need(wro + num_out));
+    if (rc) return rc;
+    HalfArgs a;
+    a.rd = rd_before;
+    a.out_abs = wro_before;
+    a.count = num_out;
+    a.C = C_;
+    a.ncoef = sp.hb_n;
+    a.pre = sp.pre;
+    for (int k = 0; k < 13; ++k) a.coef[k] = k < sp.hb_n ? sp.hb[k] : 0.0;
+    const int pi = prof_begin(false);
+    const char *kn = nullptr;
+    HIP_TRY(launch_half(src_f32, dst_f32, src_f32 ? f32_view(i, &ein, nullptr) : nof, src_f32 ? nod : f64_view(i),
+                        dst_f32 ? f32_view(i + 1, nullptr, &eout) : nof, dst_f32 ? nod : f64_view(i + 1), a, stream_, &kn));
+    prof_name(pi, kn);
+    prof_end(pi);
+  }
+  if (2 * num_out <= occ) rd += 2 * num_out; // fifo_read refuses to over-read, fifo.h:169
+  wro += num_out;
+  return kOk;
+}
+#undef RSMP_STAGE_LOCALS
+
 // Append `isamp` frames that live in device memory at d_in ([stream][frame][ch], `stride_frames`
 // between streams) and run the chain.  If d_out is given and the output fifo is empty, up to
 // out_cap produced frames are written straight into d_out (and counted as pulled).
 int Engine::feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
-                 size_t *direct_out)
+                 size_t *direct_out, bool keep_direct)
 {
   if (poisoned_) return kInternal;
   // from here on the counters move together with the launches: any failure leaves them skewed -> poison the handle
-  return fail(feed_impl(d_in, stride_frames, isamp, d_out, out_stride, out_cap, direct_out));
+  return fail(feed_impl(d_in, stride_frames, isamp, d_out, out_stride, out_cap, direct_out, keep_direct));
+}
+
+// The frames the mirror still holds move into the device ring of the output fifo (same absolute indices), so that every
+// other reader finds the whole fifo in one place.
+int Engine::spill_mirror()
+{
+  const int f = int(rings_.size()) - 1;
+  const long long base = mir_begin_, a0 = std::max(book_.rd[f], mir_begin_), a1 = mir_end_;
+  mir_begin_ = mir_end_ = 0;
+  if (a1 <= a0) return kOk;
+  int rc = ensure_ring(f, book_.wr[f] - book_.rd[f]);
+  if (rc) return rc;
+  F32View dst = f32_view(f, nullptr, nullptr), src = dst;
+  src.ext = pin_mir_.p; // frame `base` of stream 0
+  src.ext_begin = base;
+  src.ext_end = a1;
+  src.ext_stream_stride = (long long)mir_stride_ * nch_;
+  F64View nod = {};
+  HIP_TRY(launch_copy(true, src, nod, dst, nod, a0, a1, C_, stream_));
+  return kOk;
 }
 
 int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
-                      size_t *direct_out)
+                      size_t *direct_out, bool keep_direct)
 {
+  if (!keep_direct && mir_end_ > mir_begin_) { // (a push that does not mirror, a device push / flow: one place for the fifo)
+    int rcs = spill_mirror();
+    if (rcs) return rcs;
+  }
   if (direct_out) *direct_out = 0;
   ExtIn ein;
   ein.ptr = d_in;
@@ -1246,8 +1332,10 @@ int Engine::feed_impl(const float *d_in, size_t stride_frames, size_t isamp, flo
   if (eout.ptr) {
     const long long produced = book_.wr.back() - wr_out0;
     const long long direct = std::min<long long>(produced, (long long)out_cap);
-    book_.rd.back() += direct;
-    book_.samples_out += size_t(direct);
+    if (!keep_direct) {
+      book_.rd.back() += direct;
+      book_.samples_out += size_t(direct);
+    }
     if (direct_out) *direct_out = size_t(direct);
   }
   return kOk;
@@ -1267,6 +1355,54 @@ int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
   if (!ibuf || !isamp) return kOk;
   if (isamp > plan_.isamp_max) isamp = plan_.isamp_max;
   const size_t need = isamp * size_t(nch_) * size_t(S_);
+  const size_t row = isamp * nch_ * sizeof(float);
+  if (need * sizeof(float) <= kZeroCopyMaxBytes) {
+    // plugin-sized push: the kernels read it in place from the page-locked slot; the slot is released by an event behind the
+    // push's last kernel (two slots alternate, so this only ever waits for the push before the previous one)
+    Pinned &slot = pin_in_[pin_k_ ^= 1];
+    if (slot.pending) {
+      HIP_TRY(hipEventSynchronize(slot.done));
+      slot.pending = false;
+    }
+    int rp = pinned_reserve(slot, need);
+    if (rp) return rp;
+    for (int s = 0; s < S_; ++s) std::memcpy(slot.p + size_t(s) * isamp * nch_, ibuf + size_t(s) * stream_stride * nch_, row);
+    // mirror the output when the fifo is empty (the plugin pulls until it is): the exact number of frames this push makes
+    // available comes from a dry run of the counters
+    float *mir = nullptr;
+    size_t cap = 0;
+    if (!plan_.stages.empty() && available() == 0 && mir_end_ == mir_begin_) { // (no stages: the input ring IS the output fifo)
+      Book trial = book_;
+      const ExtIn no_in;
+      const ExtOut no_out;
+      for (size_t done = 0; done < isamp;) {
+        const size_t n = std::min(slab_frames_, isamp - done);
+        int rc = advance(trial, n, false, no_in, no_out);
+        if (rc) return rc;
+        done += n;
+      }
+      cap = size_t(trial.wr.back() - trial.rd.back());
+      if (cap && cap * size_t(nch_) * size_t(S_) * sizeof(float) <= kZeroCopyMaxBytes) {
+        int rm = pinned_reserve(pin_mir_, cap * size_t(nch_) * size_t(S_));
+        if (rm) return rm;
+        mir = pin_mir_.p;
+      }
+    }
+    size_t direct = 0;
+    const long long wr0 = book_.wr.back();
+    int rc = feed(slot.p, isamp, isamp, mir, cap, mir ? cap : 0, &direct, true);
+    if (rc) return rc;
+    if (mir) {
+      mir_begin_ = wr0;
+      mir_end_ = wr0 + (long long)direct;
+      mir_stride_ = cap;
+      HIP_TRY(hipEventRecord(pin_mir_.done, stream_)); // what RR_pull waits for
+      pin_mir_.pending = true;
+    }
+    HIP_TRY(hipEventRecord(slot.done, stream_));
+    slot.pending = true;
+    return kOk;
+  }
   if (need > stage_floats_) {
     HIP_TRY(hipStreamSynchronize(stream_));
     if (d_stage_) (void)hipFree(d_stage_);
@@ -1275,7 +1411,6 @@ int Engine::push_host(const float *ibuf, size_t stream_stride, size_t isamp)
     ALLOC_TRY(&d_stage_, need * sizeof(float));
     stage_floats_ = need;
   }
-  const size_t row = isamp * nch_ * sizeof(float);
   if (need * sizeof(float) <= kPinnedMaxBytes) {
     Pinned &slot = pin_in_[pin_k_ ^= 1];
     if (slot.pending) { // the copy that last used this slot (two pushes ago) must have left it
@@ -1347,8 +1482,26 @@ int Engine::pull_host(float *obuf, size_t stream_stride, size_t osamp, size_t *o
   }
   const size_t n = std::min(osamp, available());
   if (n) {
-    int rc = copy_out(obuf, S_ > 1 ? stream_stride : n, n, true);
-    if (rc) return rc;
+    const long long rd = book_.rd.back();
+    if (mir_end_ > mir_begin_ && rd >= mir_begin_ && rd + (long long)n <= mir_end_) {
+      // everything asked for sits in the page-locked mirror of the last push: wait for that push, copy on the CPU
+      if (pin_mir_.pending) {
+        HIP_TRY(hipEventSynchronize(pin_mir_.done));
+        pin_mir_.pending = false;
+      }
+      const size_t dstride = S_ > 1 ? stream_stride : n;
+      for (int s = 0; s < S_; ++s)
+        std::memcpy(obuf + size_t(s) * dstride * nch_, pin_mir_.p + (size_t(s) * mir_stride_ + size_t(rd - mir_begin_)) * nch_,
+                    n * nch_ * sizeof(float));
+      if (rd + (long long)n == mir_end_) mir_begin_ = mir_end_ = 0;
+    } else {
+      if (mir_end_ > mir_begin_) { // the request reaches past the mirror: the device ring takes what is left of it first
+        int rcs = fail(spill_mirror());
+        if (rcs) return rcs;
+      }
+      int rc = copy_out(obuf, S_ > 1 ? stream_stride : n, n, true);
+      if (rc) return rc;
+    }
     book_.rd.back() += (long long)n;
     book_.samples_out += n; // rate_base.h:448
   }
@@ -1368,6 +1521,10 @@ int Engine::pull_device(float *obuf, size_t stream_stride, size_t osamp, size_t 
   }
   const size_t n = std::min(osamp, available());
   if (n) {
+    if (mir_end_ > mir_begin_) {
+      int rcs = fail(spill_mirror());
+      if (rcs) return rcs;
+    }
     int rc = copy_out(obuf, S_ > 1 ? stream_stride : n, n, false);
     if (rc) return rc;
     book_.rd.back() += (long long)n;
@@ -1449,6 +1606,7 @@ int Engine::drain()
   }
   book_.trimmed += book_.wr.back() - (book_.rd.back() + (long long)remaining);
   book_.wr.back() = book_.rd.back() + (long long)remaining; // fifo_trim_to
+  if (mir_end_ > book_.wr.back()) mir_end_ = std::max(mir_begin_, book_.wr.back()); // (the trim can cut into frames the host mirror holds)
   book_.samples_in = book_.samples_out = 0;
   return kOk;
 }

@@ -108,12 +108,23 @@ private:
   struct ExtIn { const float *ptr = nullptr; long long begin = 0, end = 0, stride_floats = 0; };
   struct ExtOut { float *ptr = nullptr; long long begin = 0, end = 0, stride_floats = 0; };
 
+  // keep_direct: frames written straight to d_out stay in the output fifo (not counted as pulled): the host mirror
   int feed(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
-           size_t *direct_out);
+           size_t *direct_out, bool keep_direct = false);
   int feed_impl(const float *d_in, size_t stride_frames, size_t isamp, float *d_out, size_t out_stride, size_t out_cap,
-                size_t *direct_out);
+                size_t *direct_out, bool keep_direct);
   // more_slabs: another time slab of the same push follows (seam kernels may then run beside the next slab's launches)
   int advance(Book &b, size_t n_new, bool launch, const ExtIn &ein, const ExtOut &eout, bool more_slabs = false);
+  // a dft stage that is fused with the polyphase stage behind it leaves its launch to that stage
+  struct Pending { long long B0 = 0; int nblocks = 0; DftArgs args = {}; int log2n = 0, log2p = 0; };
+  // one pass of rate_process over the chain: what advance() hands to the per-stage functions
+  struct Pass { Book &b; bool launch; const ExtIn &ein; const ExtOut &eout; bool more_slabs; Pending pend; };
+  int advance_dft(Pass &ps, int i);
+  int advance_poly(Pass &ps, int i);
+  int advance_half(Pass &ps, int i);
+  int launch_fused_pair(Pass &ps, int i, long long count, long long step);
+  int launch_polymf_stage(Pass &ps, int i, long long count, long long step);
+  int launch_poly_stage(Pass &ps, int i, long long count, long long step);
   int ensure_ring(int f, long long live_needed);
   int copy_out(float *dst, size_t stride_frames, size_t frames, bool to_host);
   F32View f32_view(int f, const ExtIn *ein, const ExtOut *eout) const;
@@ -162,7 +173,6 @@ private:
   // standalone matrix-pipe polyphase stage (polymf.hip), indexed by the poly stage
   struct PolyMf { double *cfm = nullptr; int *qtab = nullptr; FusedBlock *blk = nullptr; int KS = 0, NGRP = 0, Vt = 0, blk_cap = 0; };
   std::vector<PolyMf> polymf_;
-  struct Pending { long long B0 = 0; int nblocks = 0; };
   struct ProfRec { hipEvent_t e0, e1; bool hot; const char *name; };
   std::vector<ProfRec> prof_;
   bool profiling_ = false;
@@ -182,6 +192,17 @@ private:
   Pinned pin_in_[2], pin_out_;
   int pin_k_ = 0;
   static constexpr size_t kPinnedMaxBytes = size_t(64) << 20;
+  // Plugin-sized pushes (foo_dsp_rate.cpp:182-202: 1-8 k frames, push then pull-until-empty) skip both copy commands:
+  //  * the kernels read the push straight out of the page-locked slot (it is device-visible), no H2D copy;
+  //  * when the output fifo is empty at the push, the last stage writes straight into a page-locked "mirror" of the frames
+  //    it produces ([mir_begin_, mir_end_) of the output fifo, absolute indices); RR_pull then waits for the push's last
+  //    kernel and copies from the mirror on the CPU, no D2H copy.  Frames still in the mirror when something other than a
+  //    host pull wants them (another push, a device pull, a request past its end) are first spilled into the device ring.
+  static constexpr size_t kZeroCopyMaxBytes = size_t(1) << 20;
+  Pinned pin_mir_;
+  long long mir_begin_ = 0, mir_end_ = 0; // frames of the output fifo held by the mirror (empty: begin == end)
+  size_t mir_stride_ = 0;                 // frames between streams in the mirror
+  int spill_mirror();
   int pinned_reserve(Pinned &b, size_t floats);
   void pinned_free(Pinned &b);
   size_t slab_frames_ = 0;

@@ -299,7 +299,6 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     const int t0 = (nt * wave) >> 2, t1 = (nt * (wave + 1)) >> 2; // this wave's tiles, group-major
     if (t0 >= t1) return;
     int g = t0 / ncs, c = t0 - g * ncs;
-    const int g_last = (t1 - 1) / ncs;
     const int hi_bound = min(irel_hi, ke * pl);
     const int lane_li = fb.base_li + hi + (kb + jq) * step; // window start = lane_li + q(group, block) + c * 4 * step
     const int lane_ib = (kb + jq) * pl + rloc - fb.irel_lo; // output index relative to i_lo = lane_ib + 16 g + c * 4 * pl

@@ -214,3 +214,65 @@ def test_allocation_failure_in_the_middle_of_open():
         assert R.alloc_handler_calls == before + 1, k
         assert_parity(F.Resampler(44100, 96000, 2).process(x), ref)
     assert hit >= 5
+
+
+# ------------------------------------------------------------------------------------------------ plugin-sized host pushes
+@pytest.mark.parametrize("fi,fo,nch,S", [(44100, 96000, 2, 1), (96000, 44100, 3, 1), (44100, 48000, 2, 3), (44100, 192000, 2, 1)])
+def test_host_mirror_against_oracle_call_by_call(fi, fo, nch, S):
+    """RR_push / RR_pull at plugin chunk sizes run without copy commands: the kernels read the push out of a page-locked slot
+    and write what it produces into a page-locked mirror that RR_pull copies from.  Random push sizes and PARTIAL pulls (so that
+    frames stay behind in the mirror while the next push arrives, a later pull crosses from the mirror into the device ring,
+    a device pull and a drain find frames in the mirror): every call's frame count and samples against the oracle."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(fi + fo + nch + S)
+    total = 120000
+    xs = [lcg_noise(total, nch, 70 + s).reshape(total, nch) for s in range(S)]
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S)
+    os_ = [Oracle(fi, fo, nch) for _ in range(S)]
+    pos = 0
+    step = 0
+    while pos < total - 9000:
+        n = int(rng.choice([1, 7, 256, 1024, 1024, 2048, 4096, 8192, 3000, 9000]))
+        seg = [x[pos:pos + n] for x in xs]
+        r.push(seg[0] if S == 1 else np.stack(seg))
+        for o, sg in zip(os_, seg):
+            o.push(sg)
+        pos += n
+        step += 1
+        mode = step % 5
+        want = int(rng.integers(0, int(n * fo / fi) + 300))
+        if mode == 0:
+            continue  # leave everything where it is: the next push finds frames in the mirror
+        if mode == 3 and S == 1:  # device pull of part of what is there
+            t = torch.zeros((max(want, 1), nch), device="cuda")
+            got_n = r.pull_device(t, want) if want else 0
+            r.sync()
+            ref = os_[0].pull(want) if want else np.empty((0, nch), np.float32)
+            assert got_n == ref.shape[0], (step, got_n, ref.shape)
+            if got_n:
+                assert_parity(t[:got_n].cpu().numpy(), ref)
+            continue
+        if mode == 4:  # pull until empty, as the plugin does
+            a = r.pull_all(5000)
+            for k, o in enumerate(os_):
+                b = o.pull_all(5000)
+                ak = a if S == 1 else a[k]
+                assert ak.shape == b.shape, (step, ak.shape, b.shape)
+                if b.size:
+                    assert_parity(ak, b)
+            continue
+        a = r.pull(want) if want else None  # partial pull
+        for k, o in enumerate(os_):
+            b = o.pull(want) if want else np.empty((0, nch), np.float32)
+            ak = np.empty((0, nch), np.float32) if a is None else (a if S == 1 else a[k])
+            assert ak.shape == b.shape, (step, ak.shape, b.shape)
+            if b.size:
+                assert_parity(ak, b)
+    r.drain()
+    a = r.pull_all()
+    for k, o in enumerate(os_):
+        o.drain()
+        b = o.pull_all()
+        ak = a if S == 1 else a[k]
+        assert ak.shape == b.shape
+        assert_parity(ak, b)
