@@ -121,8 +121,8 @@ def cpu_baseline(cfg, seconds_single=4.0, seconds_multi=8.0):
 
 
 def lookup_traffic(config, streams, frames, kernels):
-    """HBM bytes per step of `kernels` (one launch each per step) from the tracked PMC passes (profiles/traffic.json);
-    None unless every one of them has a record for exactly this workload."""
+    """HBM bytes per STEP of `kernels` (all launches of each within one step) from the tracked PMC passes
+    (profiles/traffic.json); None unless every one of them has a record for exactly this workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             recs = json.load(f)["records"]
@@ -132,9 +132,9 @@ def lookup_traffic(config, streams, frames, kernels):
     for k in kernels:
         hit = [r for r in recs if r.get("config") == config and r.get("streams_per_gpu") == streams and
                r.get("frames_per_push") == frames and r.get("kernel") == k]
-        if not hit or hit[0].get("hbm_bytes_per_launch") is None:
+        if not hit or hit[0].get("hbm_bytes_per_step") is None:
             return None
-        total += hit[0]["hbm_bytes_per_launch"]
+        total += hit[0]["hbm_bytes_per_step"]
     return total
 
 
@@ -376,10 +376,10 @@ def main():
                        "out_frames_per_stream": out_frames},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-                         # PMC bytes of the dominant kernel's launch (fused chain) or of the chain's stage kernels per step
-                         "traffic": (lookup_traffic(args.config, S, P, [dom["kernel"]]) if fused and launches_per_step == 1 else
-                                     lookup_traffic(args.config, S, P, [k["kernel"] for k in chain])
-                                     if all(k["launches"] == args.steps for k in chain) else None),
+                         # PMC bytes per launch of the dominant kernel (fused chain: its bytes per step / its launches per step,
+                         # like `achieved`) or per step of the chain's stage kernels together (modular chain)
+                         "traffic": ((lambda t: None if t is None else round(t / max(1.0, launches_per_step)))(lookup_traffic(args.config, S, P, [dom["kernel"]]))
+                                     if fused else lookup_traffic(args.config, S, P, [k["kernel"] for k in chain])),
                          "kernel": dom["kernel"],
                          "kernel_time_basis": "dominant kernel (fused chain)" if fused else "sum of the chain's stage kernels",
                          "launches_per_step": launches_per_step,

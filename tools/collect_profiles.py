@@ -66,15 +66,17 @@ def bench_name(kern):
     return re.sub(r"(dftx_kernel<\d+), \d+>", r"\1>", kern)
 
 
+PMC_STEPS = 7  # tools/gpu_evidence.sh runs the counter passes as `bench.py --steps 3 --warmup 1`: 1 + 3 timed + 3 in the profiling pass
+
+
 def per_step(pass_summary, counter):
-    tot, disp = collections.defaultdict(float), collections.defaultdict(int)
+    """counter total of every kernel name over the pass / the pass's step count (a step may be several launches of a kernel:
+    a push cut into slabs, dftx instances at a ring wrap)"""
+    tot = collections.defaultdict(float)
     for kern, cs in pass_summary.items():
         if counter in cs:
             tot[bench_name(kern)] += cs[counter]["mean"] * cs[counter]["dispatches"]
-            disp[bench_name(kern)] += cs[counter]["dispatches"]
-    once = [n for k, n in disp.items() if "dftx" not in k and "copy" not in k]
-    steps = min(once) if once else 1
-    return {k: v / steps for k, v in tot.items()}, steps
+    return {k: v / PMC_STEPS for k, v in tot.items()}, PMC_STEPS
 
 
 records = []
@@ -92,14 +94,14 @@ for k in (0, 1, 2, 3, 4):
             continue
         f_kb, w_kb = fe[kern], wr[kern]
         records.append({"config": k, "streams_per_gpu": cfg["streams_per_gpu"], "frames_per_push": cfg["frames_per_push"], "kernel": kern,
-                        "fetch_size_kb_raw": f_kb, "write_size_kb": w_kb, "hbm_bytes_per_launch": int(round(f_kb * 1024 * 2 + w_kb * 1024))})
-json.dump({"_comment": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_evidence.sh): "
+                        "fetch_size_kb_raw": f_kb, "write_size_kb": w_kb, "hbm_bytes_per_step": int(round(f_kb * 1024 * 2 + w_kb * 1024))})
+json.dump({"_comment": "HBM bytes per bench STEP of each kernel name (all of its launches in one step) from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_evidence.sh): "
                        "FETCH_SIZE KB x 1024 x 2 (gfx950 reports half of a streaming read, MI355X_MICROARCH.md) + WRITE_SIZE KB x 1024. "
                        "bench.py looks a workload up by (config, streams, frames, kernel) and prints null when nothing matches. "
                        "Written by tools/collect_profiles.py.",
            "records": records}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 for r in records:
-    print(r["config"], r["kernel"], "%.0f MB" % (r["hbm_bytes_per_launch"] / 1e6))
+    print(r["config"], r["kernel"], "%.0f MB" % (r["hbm_bytes_per_step"] / 1e6))
 for ln in lines:
     d = json.loads(ln)
     print(d["config"]["workload"][:28], d["n_gpus"], d["value"], d["roofline"]["frac"], d["roofline"].get("traffic"))
