@@ -102,7 +102,7 @@ template <int DIR> __device__ __forceinline__ void fft8x(c64 (&u)[8], int tid, c
 } // namespace
 
 // OKIND = 1 / 2: every block of the launch reads one contiguous span and writes one contiguous span of float frames /
-// of the planar fp64 rings (launch_dftx checks that on the host with pair_span's own predicate, span_contiguous), and the
+// of the planar fp64 rings (launch_dftx checks that on the host by calling pair_span itself, span_contiguous), and the
 // kernel has no other path -- which is what lets the compiler count the stores between a load and its use;
 // OKIND = 0 (generic): any block, element-wise fifo addressing where a span is split
 // (ring wrap, a block half in the ring and half in the caller's buffer, odd channel count) -- same arithmetic, so which
@@ -245,18 +245,18 @@ template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kern
   }
 }
 
-// host mirror of pair_span's contiguity test for `len` samples of a channel pair starting at absolute index a0
+// Do `len` samples starting at absolute index a0 lie contiguously for EVERY channel pair of the launch?  Asked of pair_span
+// itself (the function the kernel uses), for the pairs that can differ in the answer: alignment depends on the pair only
+// through its stream (stream stride) -- first pair, first pair of the second stream, last pair.  The lean instances have no
+// other path and trap if the kernel's own pair_span ever disagrees with this.
 static bool span_contiguous(const AnyView &v, long long a0, long long len, int C)
 {
-  if (v.is_f32) {
-    if ((v.f.nch & 1) || (C & 1)) return false;
-    if (v.f.ext && a0 >= v.f.ext_begin && a0 + len <= v.f.ext_end)
-      return ((reinterpret_cast<unsigned long long>(v.f.ext) | (unsigned long long)(v.f.ext_stream_stride * 4)) & 7) == 0;
-    if ((!v.f.ext || a0 + len <= v.f.ext_begin || a0 >= v.f.ext_end) && (a0 & v.f.ring_mask) + len <= v.f.ring_mask + 1)
-      return ((reinterpret_cast<unsigned long long>(v.f.ring) | (unsigned long long)(v.f.ring_stream_stride * 4)) & 7) == 0;
-    return false;
-  }
-  return (a0 & v.d.mask) + len <= v.d.mask + 1;
+  if (v.is_f32 && ((v.f.nch & 1) || (C & 1))) return false;
+  const int npairs = C / 2, hp = v.is_f32 ? v.f.nch / 2 : npairs;
+  const int want = v.is_f32 ? 1 : 2;
+  for (int pair : {0, hp < npairs ? hp : 0, npairs - 1})
+    if (pair_span(v, pair, true, a0, len).kind != want) return false;
+  return true;
 }
 
 template <int LL, int OKIND> static hipError_t launch_dftx_run(const AnyView &in, const AnyView &out, const DftArgs &a, hipStream_t st)

@@ -54,6 +54,7 @@ const Knobs &knobs()
     r.occ = on("RSMP_OCC");
     r.test_hooks = on("RSMP_TEST_HOOKS");
     if (const char *v = getenv("RSMP_SLAB_MB")) r.slab_mb = atof(v) > 0 ? atof(v) : r.slab_mb;
+    if (const char *v = getenv("RSMP_SEAM_RING_MB")) r.seam_ring_mb = atof(v) > 0 ? atof(v) : r.seam_ring_mb;
     if (const char *v = getenv("RSMP_LDS_PAD")) r.lds_pad = size_t(std::max(0, atoi(v)));
 #ifdef RSMP_EXPERIMENTS
     if (const char *v = getenv("RSMP_DBG")) r.dbg = atoi(v);
@@ -310,10 +311,11 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     fu.span = p.n + dmax;
     fu.NG = NG;
     fu.KC = threads / NG;
-    // blocks per launch: as many as a seam ring of at most 320 MB allows (two launches worth of slots: seam(k) still
+    // blocks per launch: as many as a seam ring of at most 1280 MB allows (0.4 % of the card; round 2's 320 MB cut a 963 379-frame
+    // push of 256 stereo streams into three launches, each with its own prep / seam kernels and gaps; two launches worth of slots: seam(k) still
     // reads its slots while fused(k+1) fills the next ones)
     fu.blk_cap = 64;
-    while (fu.blk_cap < kFusedMaxBlocks && size_t(C_ + 1) * size_t(4 * fu.blk_cap) * 512 <= (size_t(320) << 20)) fu.blk_cap *= 2;
+    while (fu.blk_cap < kFusedMaxBlocks && double(C_ + 1) * double(4 * fu.blk_cap) * 512 <= kn.seam_ring_mb * 1048576.0) fu.blk_cap *= 2;
     fu.slots = 2 * fu.blk_cap;
     ALLOC_TRY(&fu.blk_dev, size_t(2 * fu.blk_cap) * sizeof(FusedBlock)); // two halves: launch k uses half k & 1 (see advance)
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);

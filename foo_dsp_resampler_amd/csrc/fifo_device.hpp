@@ -169,7 +169,8 @@ template <int NPTS, typename CT> __device__ __forceinline__ void span_load(const
   }
 }
 
-__device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len, int ca = -1)
+// (__host__ too: the launchers that pick a lean kernel instance ask this very function, not a copy of its predicate)
+__host__ __device__ __forceinline__ PairSpan pair_span(const AnyView &v, int pair, bool hasb, long long a0, long long len, int ca = -1)
 {
   if (ca < 0) ca = 2 * pair; // (pair_channels: differs only with an odd channel count per stream, where float frames are never contiguous pairs)
   PairSpan r;

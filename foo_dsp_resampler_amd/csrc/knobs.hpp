@@ -7,6 +7,7 @@
 //   RSMP_NO_SIDE          seam kernels on the main stream instead of the side stream
 //   RSMP_NO_GRAPH         small pushes launch their kernels one by one instead of replaying a captured HIP graph
 //   RSMP_SLAB_MB=n        fp64 fifo budget of a time slab (default 1536)
+//   RSMP_SEAM_RING_MB=n   budget of a fused chain's seam ring (default 1280): bounds the blocks per launch (tests force many launches per push)
 //   RSMP_STAMPS=1         per-phase cycle sums of the fused kernels (s_memtime), printed when the handle closes
 //   RSMP_LDS_PAD=n / RSMP_OCC=1   occupancy experiments of fused_kernel (more LDS per workgroup / print blocks per CU)
 //   RATELIB_AMD_DEVICES=all | i,j,...   RR_open / RRX_open_batch deal new handles round-robin over these devices
@@ -74,7 +75,7 @@ struct Knobs {
   bool no_fuse = false, no_mfma = false, no_polymf = false, no_fast = false, no_dftx = false, no_polyi = false,
        no_polycoop = false, spread_vector = false, no_side = false, no_graph = false, stamps = false, occ = false,
        test_hooks = false;
-  double slab_mb = 1536.0;
+  double slab_mb = 1536.0, seam_ring_mb = 1280.0;
   size_t lds_pad = 0;
   int dbg = 0; // RSMP_DBG ablation bits: honoured in -DRSMP_EXPERIMENTS builds only
 };

@@ -276,3 +276,39 @@ def test_host_mirror_against_oracle_call_by_call(fi, fo, nch, S):
         ak = a if S == 1 else a[k]
         assert ak.shape == b.shape
         assert_parity(ak, b)
+
+
+def test_many_launches_per_push():
+    """A seam ring squeezed to 4 MB (RSMP_SEAM_RING_MB, read once per process: own process) cuts one push of 64 stereo
+    streams x 300 000 frames into 64-block launches, ~3 per push: seam kernels on the side stream beside the next launch, block
+    table halves and seam-ring slots reused within the push -- the situation in which round 2 lost seam outputs.
+    Three streams against the oracle over two pushes and a drain."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, torch, foo_dsp_resampler_amd as F, bench\n"
+        "from oracle_binding import Oracle\n"
+        "from parity import assert_parity\n"
+        "S, n, nch, fi, fo = 64, 300000, 2, 44100, 48000\n"
+        "r = F.Resampler(fi, fo, nch=nch, nstreams=S)\n"
+        "x = bench.lcg_noise_device(torch, S, n, nch, 999, 'cuda')\n"
+        "r.set_stream(torch.cuda.current_stream().cuda_stream)\n"
+        "r.profile(True)\n"
+        "cap = int(n * fo / fi) + 65536\n"
+        "ys, ogs = [], []\n"
+        "for _ in range(2):\n"
+        "    y = torch.zeros((S, cap, nch), device='cuda'); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
+        "launches = max(k['launches'] for k in r.profile_report() if 'fused' in k['kernel'] and 'prep' not in k['kernel'])\n"
+        "r.profile(False)\n"
+        "for _ in range(2):\n"
+        "    y = torch.zeros((S, cap, nch), device='cuda'); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
+        "r.drain(); tail = torch.zeros((S, 16384, nch), device='cuda'); og2 = r.pull_device(tail, 16384); r.sync()\n"
+        "for s in (0, 31, 63):\n"
+        "    o = Oracle(fi, fo, nch); xs = x[s].cpu().numpy()\n"
+        "    for k in range(4):\n"
+        "        o.push(xs); ref = o.pull_all(1 << 20)\n"
+        "        assert ref.shape[0] == ogs[k]; assert_parity(ys[k][s, :ogs[k]].cpu().numpy(), ref)\n"
+        "    o.drain(); assert_parity(tail[s, :og2].cpu().numpy(), o.pull_all())\n"
+        "print('ok', launches)\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSMP_SEAM_RING_MB="4"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-500:], p.stderr[-2000:])
+    assert int(p.stdout.split()[1]) >= 6, p.stdout  # at least three launches per push in the profiled pushes (main-stream seams) ...
