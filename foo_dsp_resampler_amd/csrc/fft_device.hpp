@@ -122,6 +122,8 @@ constexpr int fft_twiddle_count(int log2m)
 // elements (R0*16 bytes = a multiple of the 128-byte write bank row for R0 >= 8): an 8-way bank
 // conflict on ds_write_b128.  One 16-byte pad per R0 elements makes the lane stride R0+1 elements.
 template <int R0> __device__ __forceinline__ constexpr int lds_phys(int i) { return R0 >= 8 ? i + i / R0 : i; }
+// same for an index known to be non-negative (a shift instead of a signed division when the compiler cannot see the sign)
+template <int R0> __device__ __forceinline__ constexpr int lds_phys_u(unsigned i) { return R0 >= 8 ? int(i + i / unsigned(R0)) : int(i); }
 // doubles of LDS an M-point transform needs (non-split) including that padding
 constexpr int fft_lds_doubles(int log2m)
 {
@@ -155,11 +157,64 @@ template <bool BAR> __device__ __forceinline__ void rsmp_xbar()
 {
   if (BAR) (__syncthreads)();
 }
-template <int T, int MODE, int PADR = 1, bool BAR = true>
+// BYTHREAD (MODE 2 only): all 16 destinations of a thread lie in the same half of the image -- the lower one for tid < T / 2 --
+// which holds for every radix-16 pass whose butterfly stride NS is at most T / 2 (destinations of thread tid fill
+// [16 NS q, 16 NS (q + 1)), q = tid / NS).  The two rounds are then one uniform branch per wave each instead of 16 per-element
+// range tests with predicated stores (~60 vector instructions per exchange).
+template <int T, int MODE, int PADR = 1, bool BAR = true, bool BYTHREAD = false>
 __device__ __forceinline__ void lds_exchange(c64 (&v)[16], const int (&pos)[16], int tid, bool active, double *lds)
 {
 #define __syncthreads() rsmp_xbar<BAR>()
-  if (MODE == 2) {
+  if (MODE == 2 && BYTHREAD) {
+    constexpr int H = 8 * T; // M / 2
+    double2 *l2 = reinterpret_cast<double2 *>(lds);
+    const bool lower = tid < T / 2;
+    c64 lo[8];
+    // reads: element tid + s T sits at phys(tid) + s (T + T / pad period) (T is a multiple of the pad period)
+    static_assert(PADR < 8 || T % PADR == 0, "lds_exchange: pad period must divide T");
+    constexpr int RS = T + (PADR >= 8 ? T / PADR : 0);
+    int rb = lds_phys_u<PADR>(unsigned(tid));
+    asm volatile("" : "+v"(rb));
+    const double2 *const src = l2 + rb;
+    // A thread's destinations are pos[0] + (compile-time offsets): with the padded image (first pass: pos[0] = 16 tid, offsets
+    // r < 16 = the pad period) phys(pos[0] + d) = phys(pos[0]) + d, without padding phys is the identity -- one address per
+    // thread and round, the rest are immediates of the stores.
+    // (the base index is made opaque: folded into other address arithmetic it leaves the stores offsets that are negative or
+    // do not fit the 16-bit immediate, i.e. one add per store again)
+    if (active && lower) {
+      int b0 = lds_phys_u<PADR>(unsigned(pos[0]));
+      asm volatile("" : "+v"(b0));
+      double2 *const dst = l2 + b0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dst[pos[s] - pos[0]] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        double2 q = src[s * RS];
+        lo[s] = {q.x, q.y};
+      }
+    }
+    __syncthreads();
+    if (active && !lower) { // (pos >= H for these threads)
+      int b1 = lds_phys_u<PADR>(unsigned(pos[0] - H));
+      asm volatile("" : "+v"(b1));
+      double2 *const dst = l2 + b1;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dst[pos[s] - pos[0]] = make_double2(v[s].x, v[s].y);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        double2 q = src[s * RS];
+        v[s + 8] = {q.x, q.y};
+        v[s] = lo[s];
+      }
+    }
+    __syncthreads();
+  } else if (MODE == 2) {
     // a thread's 16 values may all belong to the second round, so the first round's reads need their own
     // registers until the second round's writes are out
     constexpr int H = 8 * T; // M / 2
@@ -310,7 +365,7 @@ __device__ __forceinline__ void fft_pass(c64 (&v)[16], int tid, bool active, con
 #pragma unroll
       for (int r = 0; r < R; ++r) pos[t + NB * r] = (j - k) * R + k + r * NS;
     }
-    lds_exchange<T, MODE, (NS == 1 && MODE != 1) ? R : 1, !(RSMP_EXP_NOBAR && NS > 1)>(v, pos, tid, active, lds);
+    lds_exchange<T, MODE, (NS == 1 && MODE != 1) ? R : 1, !(RSMP_EXP_NOBAR && NS > 1), (MODE == 2 && R == 16 && 2 * NS <= T)>(v, pos, tid, active, lds);
   }
 }
 
@@ -405,10 +460,14 @@ __device__ __forceinline__ void fft8_pass(c64 (&u)[8], int tid, const double2 *_
       }
     }
     if (!(RSMP_EXP_NOBAR >= 2 && NS > 1)) __syncthreads();
-    if (active) {
+    if (active) { // element tid + s T8 sits at phys(tid) + s (T8 + T8 / pad period): one address, seven immediates
+      constexpr int RS = T8 + (PADR >= 8 ? T8 / PADR : 0);
+      int rb = lds_phys_u<PADR>(unsigned(tid));
+      asm volatile("" : "+v"(rb));
+      const double2 *const src = l2 + rb;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const double2 q = l2[lds_phys<PADR>(tid + s * T8)];
+        const double2 q = src[s * RS];
         u[s] = {q.x, q.y};
       }
     }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       if (ld_active) {
 #pragma unroll
         for (int s = 0; s < NLD; ++s) {
-          const float2 f = p2[(tid + s * TL) * hp];
+          const float2 f = p2[(unsigned)((tid + s * TL) * hp)]; // (unsigned: scalar base + 32-bit lane offset, no 64-bit address per load)
           (FWD8 ? u8[s & 7] : v[s]) = {(double)f.x, (double)f.y};
         }
       }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       fft8_regs_pre<LOG2P, -1>(u8, tid, wf, lds, [&](int p) {
         if (p == 1) { // two passes (two LDS round trips) ahead of the multiplication
 #pragma unroll
-          for (int s = 0; s < 16; ++s) g[s] = (RSMP_EXP_SKIP & 128) ? make_double2(1e-3 * s, 1e-4 * tid) : load_g(Gp + tid + (RSMP_EXP_TAB & 2 ? 0 : s * T));
+          for (int s = 0; s < 16; ++s) g[s] = (RSMP_EXP_SKIP & 128) ? make_double2(1e-3 * s, 1e-4 * tid) : load_g(Gp + (unsigned)(tid + (RSMP_EXP_TAB & 2 ? 0 : s * T)));
         }
       });
     } else { // G in flight during the whole forward transform
