@@ -50,14 +50,17 @@ def test_cfg4_per_gpu_shard_against_oracle():
 
 
 def test_enomem_runs_the_handler_once_and_leaves_no_handle():
-    """An allocation the device cannot satisfy: RR_ENOMEM, the init_ratelib handler runs exactly once from the
-    calling host frame (xmalloc.c:38-43, rate_uni.c:31-53), *handle stays NULL, and the library keeps working."""
+    """A request no device could hold fifos for (4 M channels) is answered by the parameter guard in Engine::create before
+    any allocation: RR_ENOMEM, the init_ratelib handler runs exactly once from the calling host frame (xmalloc.c:38-43,
+    rate_uni.c:31-53), *handle stays NULL, and the library keeps working.  (A REAL device allocation failing in the middle of a
+    handle's construction, and the teardown of the half-built engine, is tests/test_gpu_round3.py::
+    test_allocation_failure_in_the_middle_of_open.)"""
     L = F.lib()
     R._ensure_init()
     before = R.alloc_handler_calls
     cfg = F.RRConfig(44100, 96000, 50.0, 95.0, 0, 0)
     h = C.c_void_p(0x1234)
-    rc = L.RRX_open_batch(C.byref(cfg), 2, 1 << 21, C.byref(h))   # 4 M channels: far more fifo memory than one GPU has
+    rc = L.RRX_open_batch(C.byref(cfg), 2, 1 << 21, C.byref(h))   # 4 M channels: refused by the guard, nothing is allocated
     assert rc == 1 and not h.value                                # RR_ENOMEM
     assert R.alloc_handler_calls == before + 1
     assert L.RR_strerror(rc).decode() == "Not enough memory"
