@@ -317,6 +317,8 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
     # stream 0's output of the last timed step, kept for the check (the profiling pass below overwrites y)
     y_last = y[0, :last_og[0]].clone() if args.check and rank == 0 else None
+    torch.cuda.synchronize()  # the copy runs on torch's current stream, the engine on `stream`: it must have finished before the
+    #                           profiling pass overwrites y (two ranks sharing one GPU lost that race: "checked": false on good data)
 
     # second pass of the same K steps with HIP events around every stage launch (profiling keeps all
     # kernels on one stream, so it stays out of the pass that defines `value`)
