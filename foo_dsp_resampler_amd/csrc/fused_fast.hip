@@ -309,6 +309,10 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         __builtin_amdgcn_make_buffer_rsrc(obytes, 0, (!OUT64 && cnt > 0) ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
 #endif
     const int step4 = 4 * step, pl4 = 4 * pl;
+    // store offset of a tile = (this lane's part, once per round) + (the tile's part, scalar): one vector add per tile.  Only the
+    // last residue group can hold residues >= polyL (polyL not a multiple of 16): its lanes get the dropped offset there.
+    const int lane_off0 = __mul24(lane_ib, frame_bytes); // |lane_ib| < 2^23
+    const bool lane_dead_last = 16 * (ngrp - 1) + rloc >= pl;
 
     // Coefficient tiles: current group, next group (in flight).  The window start of a group comes with its tile (odd KS: spare
     // half of the last 16-byte element) and stays a double until the group becomes current, so that nothing waits for the
@@ -352,13 +356,16 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     int left = t1 - t0;
     // one tile: prefetch the next tile's samples into `xn`, run the two accumulation chains on `xc`, store
     auto tile = [&](const double2 (&xc)[KS], double2 (&xn)[KS]) {
-      int cnext = c + 1, gnext = g;
-      if (cnext == ncs) {
-        cnext = 0;
-        gnext = g + 1;
-      }
-      const bool switch_group = gnext != g && left > 1;
-      if (switch_group) { // uniform.  Volatile so that it STAYS a branch: as a select the conversion runs in every tile and the
+      // (loop control in plain ints: uniform bools that live across blocks came back as v_cndmask / v_readfirstlane pairs)
+      // (and every condition is recomputed from them where it is used: carried from one block to the next it takes a trip through
+      // a vector register)
+      // wrap = 1 when this is its group's last tile (c + 1 == ncs), by arithmetic the optimiser cannot see through: as a compare
+      // (+ select) it widens the flag through a vector register (v_cndmask, v_readfirstlane, v_cmp_ne) in every tile
+      int wrap, keep;
+      asm("s_lshr_b32 %0, %1, 31" : "=s"(wrap) : "s"(ncs - 2 - c));
+      asm("s_add_i32 %0, %1, -1" : "=s"(keep) : "s"(wrap) : "scc"); // all ones unless the group ends
+      const int cnext = (c + 1) & keep, gnext = g + wrap;
+      if (wrap != 0 && left > 1) { // uniform.  Volatile so that it STAYS a branch: as a select the conversion runs in every tile and the
                           // tile right behind a switch waits for the tile load that was just issued
         if constexpr (KS & 1) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(qc) : "v"(qnd));
         else asm volatile("v_mov_b32 %0, %1" : "=v"(qc) : "v"(qni));
@@ -395,7 +402,11 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
         // one unconditional buffer store per tile: outputs in front of the block (ib < 0 wraps to a huge offset) and behind
         // the round's last one fail the descriptor's range check and are dropped by the hardware; only the residue test of
         // the last (partial) group needs a select
-        const unsigned off = (16 * g + rloc < pl) ? (unsigned)__mul24(ib, frame_bytes) : 0xffffffffu; // |ib| < 2^23: full-rate multiply
+        unsigned off = (unsigned)(lane_off0 + (16 * g + c * pl4) * frame_bytes);
+        if (g == ngrp - 1 && (pl & 15)) { // uniform, and only chains whose polyL is not a multiple of 16 ever take it
+          off = lane_dead_last ? 0xffffffffu : off;
+          asm volatile("" : "+v"(off)); // (keeps it a branch: as selects it is two more vector instructions in every tile)
+        }
         const rsmp_v2u d = {__float_as_uint((float)accA), __float_as_uint((float)accB)};
         if constexpr ((RSMP_EXP_SKIP & 8) != 0) { // no stores: only a result nobody produces would be written
           if (accA == 1.2345e300) __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (int)off, 0, 0);
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       if (ib >= 0 && ib < cnt && 16 * g + rloc < pl)
         *reinterpret_cast<float2 *>(obytes + (unsigned)(ib * frame_bytes)) = make_float2((float)accA, (float)accB);
 #endif
-      if (switch_group) { // uniform
+      if (wrap != 0 && left > 1) { // uniform: the group switches
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("v_mov_b64 %0, %1" : "=v"(cc[s]) : "v"(cn[s]));
         __builtin_amdgcn_sched_barrier(0);
