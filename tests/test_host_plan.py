@@ -234,3 +234,36 @@ def test_planner_agrees_with_oracle_on_large_upsampling(fi, fo):
     for a, b in zip(plan, ref):
         if a["kind"] == "dft":
             assert (a["L"], a["step_int"], a["num_taps"], a["dft_length"]) == (b["L"], b["step_int"], b["num_taps"], b["dft_length"])
+
+
+def test_experiment_switches_cannot_reach_the_product_build():
+    """Wrong-result timing switches (RSMP_EXP_*, RSMP_DFTX_SKIP) exist only under -DRSMP_EXPERIMENTS: csrc/knobs.hpp refuses a
+    build that sets one without it, and the product Makefile never sets either."""
+    import subprocess
+    csrc = os.path.join(ROOT, "foo_dsp_resampler_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "-DRSMP_EXPERIMENTS" not in "\n".join(ln for ln in mk.splitlines() if not ln.lstrip().startswith("#"))
+    assert "RSMP_EXP_" not in "\n".join(ln for ln in mk.splitlines() if not ln.lstrip().startswith("#"))
+    src = '#include "knobs.hpp"\nint main() { return RSMP_EXP_TAB + RSMP_EXP_SKIP; }\n'
+    def compiles(flags):
+        return subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", csrc, "-x", "c++", "-"] + flags, input=src, text=True,
+                              capture_output=True).returncode == 0
+    assert compiles([])                                              # product flags: every switch is the constant 0
+    assert not compiles(["-DRSMP_EXP_TAB=1"])                        # refused ...
+    assert not compiles(["-DRSMP_EXP_SKIP=4"])
+    assert compiles(["-DRSMP_EXPERIMENTS", "-DRSMP_EXP_TAB=1"])      # ... unless the build says it is an experiment
+
+
+def test_environment_is_read_once():
+    """No getenv on the launch path: the only reads are the one-time knobs() initialiser (engine.cpp) and init_ratelib's
+    RATELIB_AMD_DEVICES (capi.cpp)."""
+    import glob
+    import re
+    hits = []
+    for path in glob.glob(os.path.join(ROOT, "foo_dsp_resampler_amd", "csrc", "*")):
+        if path.endswith((".cpp", ".hip", ".hpp")):
+            for n, ln in enumerate(open(path), 1):
+                if re.search(r"\bgetenv\s*\(", ln) and not ln.lstrip().startswith("//"):
+                    hits.append((os.path.basename(path), n))
+    assert {f for f, _ in hits} <= {"engine.cpp", "capi.cpp"}, hits
+    assert len([1 for f, _ in hits if f == "capi.cpp"]) == 1, hits
