@@ -600,7 +600,12 @@ int Engine::pinned_reserve(Pinned &b, size_t floats)
 {
   if (!b.done) HIP_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   if (b.floats >= floats) return kOk;
-  if (b.p) (void)hipHostFree(b.p);
+  if (b.p) {
+    // growing: queued work may still read or write the old block (a mirror being spilled into the device ring, a copy out of
+    // it); nothing that is queued may outlive the block
+    HIP_TRY(hipStreamSynchronize(stream_));
+    (void)hipHostFree(b.p);
+  }
   b.p = nullptr;
   b.floats = 0;
   size_t want = 4096;
