@@ -615,37 +615,40 @@ __global__ __launch_bounds__(256) void seam_kernel(AnyView out, FusedArgs a)
   // (no divisions by run-time values in the loops: thread = (row, column) of every tile it touches)
   // (all loads of a phase are issued before the first one is waited for: one memory round trip per phase, not one per row --
   // written as a plain loop the compiler waits for every load before the LDS store behind it, 16 round trips in a row)
-  { // windows [tail of B-1 | head of B]: lane k of a 64-lane row, 4 channels per pass
+  { // [r3] BOTH load phases are issued before anything is waited for (one memory round trip for the kernel's inputs, not two):
+    // windows [tail of B-1 | head of B] -- lane k of a 64-lane row, 4 channels per pass, unconditional loads from a clamped
+    // address (per-load branches made each of them its own basic block) -- and the coefficient rows of the boundary's outputs
+    // -- lane j of a 32-lane row, 8 outputs per pass, only the passes the boundary has outputs for.
     const int k = tid & 63;
     const double *const tails = a.seam + ((long long)((int)((B - 1) & a.seam_mask) * (a.d.C + 1) + c0) * 2 + 1) * 32;
     const double *const heads = a.seam + ((long long)((int)(B & a.seam_mask) * (a.d.C + 1) + c0) * 2) * 32;
-    if (k < 2 * nm1) {
-      const double *const src = k < nm1 ? tails + k : heads + (k - nm1);
-      const bool zero = k < nm1 && B == 0;
-      double t[kSeamC / 4];
+    const bool wk = k < 2 * nm1;
+    const double *const src = k < nm1 ? tails + k : heads + (min(k, 2 * nm1 - 1) - nm1);
+    const bool zero = k < nm1 && B == 0; // (B = 0: the slot read is a valid one of the ring, its value is not used)
+    double tw[kSeamC / 4];
 #pragma unroll
-      for (int i = 0; i < kSeamC / 4; ++i) {
-        const int cl = min((tid >> 6) + 4 * i, nc - 1);
-        t[i] = zero ? 0.0 : src[cl * 64];
-      }
-#pragma unroll
-      for (int i = 0; i < kSeamC / 4; ++i) {
-        const int cl = (tid >> 6) + 4 * i;
-        if (cl < nc) win[cl][k] = t[i];
-      }
-    }
-  }
-  { // coefficient rows of the boundary's outputs: lane j of a 32-lane row, 8 outputs per pass
+    for (int i = 0; i < kSeamC / 4; ++i) tw[i] = src[min((tid >> 6) + 4 * i, nc - 1) * 64];
     const int j = min(tid & 31, n - 1);
     double t[kSeamOut / 8];
     int q[kSeamOut / 8];
 #pragma unroll
     for (int i = 0; i < kSeamOut / 8; ++i) {
-      const int u = min((tid >> 5) + 8 * i, max(cnt - 1, 0));
-      const unsigned tc = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
-      const unsigned qq = tc / (unsigned)pl, ph = tc - qq * (unsigned)pl;
-      q[i] = fb.seam_q0 + (int)qq; // window start inside [tail | head], 0 <= . < n-1
-      t[i] = a.tab[(long long)ph * n + j];
+      t[i] = 0.0;
+      q[i] = 0;
+      if (8 * i < cnt) { // uniform
+        const int u = min((tid >> 5) + 8 * i, cnt - 1);
+        const unsigned tc = (unsigned)fb.seam_ph0 + (unsigned)u * (unsigned)step; // clock of output seam_i0 + u relative to window seam_q0
+        const unsigned qq = tc / (unsigned)pl, ph = tc - qq * (unsigned)pl;
+        q[i] = fb.seam_q0 + (int)qq; // window start inside [tail | head], 0 <= . < n-1
+        t[i] = a.tab[(long long)ph * n + j];
+      }
+    }
+    if (wk) {
+#pragma unroll
+      for (int i = 0; i < kSeamC / 4; ++i) {
+        const int cl = (tid >> 6) + 4 * i;
+        if (cl < nc) win[cl][k] = zero ? 0.0 : tw[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < kSeamOut / 8; ++i) {
