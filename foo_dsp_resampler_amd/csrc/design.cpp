@@ -139,16 +139,16 @@ std::vector<double> design_lowpass(double Fp, double Fs, double Fn, double att, 
   return h;
 }
 
-// lsx_fir_to_phase (effects_i_dsp.c:181-278) in EXTENDED precision (x87 long double: 64-bit significand).
+// lsx_fir_to_phase (effects_i_dsp.c:181-278) in EXTENDED precision: the first transform in binary128 (fft_q below), everything
+// behind it on x87 long double (64-bit significand), one rounding to double at the end.
 //
 // The construction takes the logarithm of the filter's spectrum; in the stop band (-180 dB for the Best filters) that
 // amplifies the rounding of whatever FFT produced the spectrum by ~1e9, so in plain fp64 the designed taps are an accident of
 // one FFT's rounding, reproducible to ~1e-7 of the peak only (round 2 measured 1.1e-6 ... 4.2e-6 relative RMS at the output
 // between this library and an independent fp64 implementation of the same steps; the reference's own Ooura transform would
-// give a third answer).  Every transform, logarithm, exponential and sine / cosine below therefore runs on long double and
-// the taps are rounded to double once, at the end: two implementations with transforms of different structure then agree
-// to 1e-10 ... 6e-9 of the peak tap (tests/test_host_plan.py), 1000x closer than in fp64.  Against the reference itself
-// the tolerance stays what fp64 Ooura arithmetic makes it: inherent ~1e-6 at the output, unpinned.
+// give a third answer).  In the precisions used here two implementations with transforms of different structure agree to a
+// few fp64 ulps of the peak tap (tests/test_host_plan.py), for 553-tap and 5000-tap filters alike.  Against the reference itself
+// the tolerance stays what its fp64 Ooura arithmetic makes it: inherent ~1e-6 at the output, unpinned.
 namespace {
 typedef long double ld;
 typedef std::complex<ld> cld;
@@ -181,6 +181,62 @@ void fft_ld(std::vector<cld> &a, int sign)
 }
 } // namespace
 
+// The FIRST transform of the construction (taps -> spectrum) in binary128 (__float128, software arithmetic: a one-off of
+// 35 ms for the 553-tap filters, ~1 s for a 5000-tap one).  It is the only ill-conditioned step: the stop-band bins are
+// 180-200 dB below the pass band, so a transform that is accurate to 1e-19 of the LARGEST bin (long double) leaves them a
+// relative error of 1e-9, which the logarithm behind it turns into the error of everything that follows -- with long double
+// alone two implementations agreed to 1e-10 of the peak tap for the 553-tap filters but only to 8.5e-8 for a 4981-tap one
+// (192k -> 11.025k at a 99 % passband, phase 10: 1.3e-7 relative RMS at the output, over the 1e-7 bar).  With the spectrum
+// exact to ~1e-33 the rest (log, two transforms, exp, one more transform) is well conditioned and stays in long double.
+namespace {
+typedef __float128 q128;
+struct cq { q128 re, im; };
+inline cq qmul(cq a, cq b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+
+// exp(i * sign * 2 pi / n) in binary128: pi as the sum of two long doubles, sine and cosine by their power series (|x| <= 0.1)
+cq unit_root_q(size_t n, int sign)
+{
+  const q128 pi = (q128)3.14159265358979323851280895940618620443274267017841339111328125L + (q128)(-5.016557612668332023557327080330757013833665769218359371379101e-20L);
+  const q128 x = 2 * pi / (q128)(long double)n, x2 = x * x;
+  q128 c = 1, s = x, tc = 1, ts = x;
+  for (int k = 1; k < 20; ++k) {
+    tc = -tc * x2 / (q128)((2 * k - 1) * (2 * k));
+    ts = -ts * x2 / (q128)((2 * k) * (2 * k + 1));
+    c += tc;
+    s += ts;
+  }
+  return {c, sign * s};
+}
+
+// iterative radix-2 decimation in time, binary128; twiddles w^k by doubling (w^(2m) = (w^m)^2, w^(2m+1) = w^(2m) w)
+void fft_q(std::vector<cq> &a, int sign)
+{
+  const size_t n = a.size();
+  int bits = 0;
+  while ((size_t(1) << bits) < n) ++bits;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t r = bit_reverse(unsigned(i), bits);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  std::vector<cq> w(n / 2 ? n / 2 : 1);
+  w[0] = {1, 0};
+  if (n >= 4) {
+    const cq w1 = unit_root_q(n, sign);
+    w[1] = w1;
+    for (size_t k = 2; k < n / 2; ++k) w[k] = (k & 1) ? qmul(w[k - 1], w1) : qmul(w[k / 2], w[k / 2]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len / 2, stride = n / len;
+    for (size_t base = 0; base < n; base += len)
+      for (size_t k = 0; k < half; ++k) {
+        const cq t = qmul(a[base + k + half], w[k * stride]), u = a[base + k];
+        a[base + k] = {u.re + t.re, u.im + t.im};
+        a[base + k + half] = {u.re - t.re, u.im - t.im};
+      }
+  }
+}
+} // namespace
+
 void to_phase(std::vector<double> &h, int &post_len, double phase)
 {
   const ld blend = ld((phase > 50 ? 100 - phase : phase) / 50); // 0: minimum phase ... 1: linear
@@ -190,8 +246,12 @@ void to_phase(std::vector<double> &h, int &post_len, double phase)
   const int half = W / 2;
 
   std::vector<cld> buf(W);
-  for (int i = 0; i < len; ++i) buf[i] = cld(ld(h[i]), 0);
-  fft_ld(buf, +1);
+  { // taps -> spectrum in binary128 (see fft_q), handed on as long double
+    std::vector<cq> sq(W, cq{0, 0});
+    for (int i = 0; i < len; ++i) sq[i].re = (q128)h[i];
+    fft_q(sq, +1);
+    for (int i = 0; i < W; ++i) buf[i] = cld((ld)sq[i].re, (ld)sq[i].im);
+  }
   buf[0] = cld(buf[0].real(), 0);       // the reference's packed real transform has no imaginary
   buf[half] = cld(buf[half].real(), 0); // part at DC / Nyquist
 

@@ -307,6 +307,61 @@ static void fft_ld(orc_ld *re, orc_ld *im, int n, int sign)
   }
 }
 
+/* The first transform (taps -> spectrum) in binary128: it alone is ill-conditioned (stop-band bins 180-200 dB below the
+ * largest one; see the product's design.cpp, which does the same with a decimation-in-time transform and a doubled twiddle
+ * table -- here: decimation in frequency, twiddles by repeated multiplication within a stage and re-seeded from the series
+ * every 64 steps). */
+typedef __float128 orc_q;
+static void unit_root_q(int n, int k, int sign, orc_q *c_out, orc_q *s_out)
+{ /* exp(i sign 2 pi k / n): argument reduced to |x| <= pi/4 by the octant symmetries, then the power series */
+  const orc_q pi = (orc_q)3.14159265358979323851280895940618620443274267017841339111328125L +
+                   (orc_q)(-5.016557612668332023557327080330757013833665769218359371379101e-20L);
+  /* angle = 2 pi k / n with 0 <= k < n/2, n a power of two >= 8: octant o = floor(8k/n), remainder r in [0, n/8) */
+  const int o = (int)((8LL * k) / n), r = k - (int)((long long)o * n / 8);
+  int kk = (o & 1) ? n / 8 - r : r; /* odd octants run backwards from the next multiple of pi/4 */
+  const orc_q x = 2 * pi * (orc_q)kk / (orc_q)n, x2 = x * x;
+  orc_q c = 1, sn = x, tc = 1, ts = x, cc, ss;
+  int t;
+  for (t = 1; t < 24; ++t) {
+    tc = -tc * x2 / (orc_q)((2 * t - 1) * (2 * t));
+    ts = -ts * x2 / (orc_q)((2 * t) * (2 * t + 1));
+    c += tc; sn += ts;
+  }
+  /* (cos, sin) of the full angle from (c, sn) of the reduced one: angle = o*pi/4 + x (even o) or (o+1)*pi/4 - x (odd o) */
+  switch (o) {
+    case 0: cc = c; ss = sn; break;           /* x */
+    case 1: cc = sn; ss = c; break;           /* pi/2 - x */
+    case 2: cc = -sn; ss = c; break;          /* pi/2 + x */
+    default: cc = -c; ss = sn; break;         /* pi - x */
+  }
+  *c_out = cc; *s_out = sign * ss;
+}
+static void fft_q(orc_q *re, orc_q *im, int n, int sign)
+{
+  int len, base, k, i, j;
+  for (len = n; len >= 2; len >>= 1) {
+    const int half = len / 2;
+    for (k = 0; k < half; ++k) {
+      orc_q c, s;
+      if (len >= 8) unit_root_q(len, k, sign, &c, &s);
+      else if (len == 4) { c = k ? 0 : 1; s = k ? sign : 0; }
+      else { c = 1; s = 0; }
+      for (base = 0; base < n; base += len) {
+        const int a = base + k, b = a + half;
+        const orc_q dr = re[a] - re[b], di = im[a] - im[b];
+        re[a] += re[b]; im[a] += im[b];
+        re[b] = dr * c - di * s; im[b] = dr * s + di * c;
+      }
+    }
+  }
+  for (i = 0, j = 0; i < n; ++i) {
+    int bit;
+    if (i < j) { orc_q t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    for (bit = n >> 1; bit && (j & bit); bit >>= 1) j ^= bit;
+    j |= bit;
+  }
+}
+
 static int g_phase_ref64 = 0;
 void orc_set_phase_arith(int ref64) { g_phase_ref64 = ref64; }
 void orc_fir_to_phase_ref64(double **h, int *len, int *post_len, double phase);
@@ -329,8 +384,13 @@ void orc_fir_to_phase(double **h, int *len, int *post_len, double phase)
   wraps = (orc_ld *)malloc(sizeof(orc_ld) * (size_t)(half + 1));
   imp = (double *)malloc(sizeof(double) * (size_t)wlen);
 
-  for (i = 0; i < *len; ++i) re[i] = (*h)[i];
-  fft_ld(re, im, wlen, +1);
+  { /* taps -> spectrum in binary128, handed on as long double */
+    orc_q *qr = (orc_q *)calloc((size_t)wlen, sizeof(orc_q)), *qi = (orc_q *)calloc((size_t)wlen, sizeof(orc_q));
+    for (i = 0; i < *len; ++i) qr[i] = (orc_q)(*h)[i];
+    fft_q(qr, qi, wlen, +1);
+    for (i = 0; i < wlen; ++i) { re[i] = (orc_ld)qr[i]; im[i] = (orc_ld)qi[i]; }
+    free(qr); free(qi);
+  }
   im[0] = 0; im[half] = 0; /* the packed real transform of the reference carries no imaginary part at DC / Nyquist */
 
   for (i = 0; i <= half; ++i) { /* :206-224 */

@@ -68,9 +68,10 @@ def check_against_oracle(fi, fo, tables=True, **kw):
             if a.size:
                 # Linear phase: same libm formulas on both sides -> identical bits.  Other phases go through the cepstral
                 # minimum-phase construction (effects_i_dsp.c:181-278): log|H| of a -180 dB stop band amplifies the rounding
-                # of whichever FFT is used by ~1e9.  Both sides run it in extended precision (long double) with transforms of
-                # different structure: ~1e-10 of the peak tap between them (fp64 on both sides: ~1e-7 ... 3e-6).
-                tol = 0 if kw.get("phase", 50.0) == 50.0 else 2e-8
+                # of whichever FFT produced the spectrum by ~1e9.  Both sides run that first transform in binary128 and the
+                # rest in long double, with transforms of different structure: they agree to a few fp64 ulps of the peak
+                # tap (fp64 on both sides: ~1e-7 ... 3e-6; long double alone: 1e-10 ... 9e-8).
+                tol = 0 if kw.get("phase", 50.0) == 50.0 else 1e-15
                 assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b))), (fi, fo, kw, which)
         a, b = F.plan_table(2, fi, fo, **kw), o.poly_table()
         assert a.shape == b.shape and (a.size == 0 or np.array_equal(a, b)), (fi, fo, kw)
@@ -91,17 +92,20 @@ def test_tables_match_oracle(fi, fo, kw):
 
 
 def test_phase_tables_agree_in_extended_precision():
-    """phase != 50: product (design.cpp, decimation in time, long double) against oracle (rate_oracle.c, decimation in frequency,
-    long double): <= 2e-8 of the peak tap.  The oracle's fp64 statement of the same function, which follows the reference line
-    by line (orc_set_phase_arith(1)), differs from either by 3e-7 ... 3e-6: the reference's own irreproducibility, the reason
-    phase != 50 is "parity unpinned" against the reference itself however well product and oracle agree."""
+    """phase != 50: product (design.cpp: first transform in binary128 by decimation in time, the rest in long double) against
+    oracle (rate_oracle.c: the same precisions, decimation in frequency, twiddles from series): <= 1e-15 of the peak tap, i.e. the
+    two tables differ by an fp64 ulp here and there.  The oracle's fp64 statement of the same function, which follows the
+    reference line by line (orc_set_phase_arith(1)), differs from either by 3e-7 ... 3e-6: the reference's own
+    irreproducibility, the reason phase != 50 is "parity unpinned" against the reference itself however well product and
+    oracle agree."""
     import ctypes
     import oracle_binding
     L = oracle_binding.lib()
     L.orc_set_phase_arith.argtypes = [ctypes.c_int]
     worst_ld, worst_64, worst_64_steep = 0.0, 0.0, 0.0
-    for fi, fo, kw in [(44100, 48000, {}), (44100, 96000, {}), (96000, 44100, {}), (44100, 192000, {"bandwidth": 99.0})]:
-        for phase in (0.0, 25.0, 75.0, 100.0):
+    for fi, fo, kw in [(44100, 48000, {}), (44100, 96000, {}), (96000, 44100, {}), (44100, 192000, {"bandwidth": 99.0}),
+                       (192000, 11025, {"bandwidth": 99.0})]:
+        for phase in (0.0, 10.0, 25.0, 75.0, 100.0):
             a = F.plan_table(0, fi, fo, phase=phase, **kw)
             b = Oracle(fi, fo, 1, phase=phase, **kw).dft_taps(0)
             L.orc_set_phase_arith(1)
@@ -116,7 +120,7 @@ def test_phase_tables_agree_in_extended_precision():
                 worst_64_steep = max(worst_64_steep, np.max(np.abs(b - c)) / pk)
             else:
                 worst_64 = max(worst_64, np.max(np.abs(b - c)) / pk)
-    assert worst_ld <= 2e-8, worst_ld  # (6e-9 for the 2845-tap filter of 44.1k->192k at 99 %; ~1e-10 for the 553-tap ones)
+    assert worst_ld <= 1e-15, worst_ld  # (2e-18 ... 5e-17 measured, the 4981-tap filter of 192k->11.025k at 99 % included)
     assert 1e-8 < worst_64 <= 1e-5, worst_64  # the fp64 construction really is that loose at the default passband ...
     # ... and at a 99 % passband with an intermediate phase it is not a function of its input any more: the stop-band bins of
     # the 2845-tap filter are rounding noise in fp64, their phase "wraps" are counted into the blend (effects_i_dsp.c:206-240),

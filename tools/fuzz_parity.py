@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Seeded random parity sweep: HIP engine vs the CPU oracle over rates, channel counts, qualities,
-bandwidths, aliasing, chunk patterns (not part of the pytest suite; run on a GPU box)."""
+bandwidths, aliasing, phases, chunk patterns (not part of the pytest suite; run on a GPU box).
+`fuzz_parity.py N SEED [PHASE_SHARE]`: PHASE_SHARE (default 0.15) of the cases use phase != 50 -- same bar."""
 import os
 import sys
 
@@ -16,7 +17,7 @@ from parity import compare_f32  # noqa: E402
 RATES = [8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 88200, 96000, 176400, 192000]
 
 
-def main(n_cases, seed):
+def main(n_cases, seed, phase_share=0.15):
     rng = np.random.RandomState(seed)
     worst = {"max_ulp": 0.0, "rel_rms": 0.0}
     bad = 0
@@ -32,6 +33,8 @@ def main(n_cases, seed):
             kw["bandwidth"] = float(rng.choice([90.0, 97.0, 99.0, 99.5]))
         if rng.rand() < 0.2:
             kw["allow_aliasing"] = 1
+        if rng.rand() < phase_share:
+            kw["phase"] = float(rng.choice([0.0, 10.0, 25.0, 40.0, 60.0, 75.0, 100.0]))
         frames = int(rng.randint(3000, 60000))
         x = lcg_noise(frames, nch, int(rng.randint(1, 1 << 30)))
         # random push pattern, identical for both sides
@@ -58,7 +61,7 @@ def main(n_cases, seed):
         rep = compare_f32(g, f)
         worst["max_ulp"] = max(worst["max_ulp"], rep["max_ulp"])
         worst["rel_rms"] = max(worst["rel_rms"], rep["rel_rms"])
-        ok = rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7  # one bar for every chain (tests/parity.py)
+        ok = rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7  # one bar for every chain and every phase (tests/parity.py)
         if not ok:
             bad += 1
             print("MISMATCH case", k, fi, fo, nch, kw, frames, cuts, rep)
@@ -67,4 +70,5 @@ def main(n_cases, seed):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 2026) else 0)
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 2026,
+                       float(sys.argv[3]) if len(sys.argv) > 3 else 0.15) else 0)
