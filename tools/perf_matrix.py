@@ -25,7 +25,7 @@ CASES = [
 ]
 
 
-def run(name, fi, fo, nch, S, kw, steps=5, frames=200000):
+def run(name, fi, fo, nch, S, kw, steps=40, frames=200000):
     r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
     P = min(frames, r.isamp_max)
     st = torch.cuda.Stream()
@@ -34,21 +34,40 @@ def run(name, fi, fo, nch, S, kw, steps=5, frames=200000):
     y = torch.empty((S, cap, nch), device="cuda")
     torch.cuda.synchronize()
     r.set_stream(st.cuda_stream)
-    for _ in range(2):
+    for _ in range(3):
         r.flow_device(x, P, y, cap)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    used = made = 0
     for _ in range(steps):
-        r.flow_device(x, P, y, cap)
+        iu, og = r.flow_device(x, P, y, cap)
+        used += iu; made += og
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    units = S * P * nch * steps
+    # every timed call must have taken its whole push and produced the chain's share of output, or the rate below is fiction
+    assert used == P * steps, (name, used, P * steps)
+    assert abs(made - used * fo / fi) <= 0.002 * made + 65536, (name, made, used * fo / fi)
+    units = S * used * nch
     bpu = 4.0 * (1 + fo / fi)
     plan = [s["kind"] for s in F.describe_plan(fi, fo, **kw)["stages"]]
     return {"case": name, "plan": "->".join(plan), "Gsamples_in_per_s": round(units / dt / 1e9, 2),
-            "hbm_frac": round(units * bpu / dt / 8e12, 4), "ms_per_step": round(dt / steps * 1e3, 3)}
+            "hbm_frac": round(units * bpu / dt / 8e12, 4), "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "frames_in": used, "frames_out": made}
 
 
 if __name__ == "__main__":
+    # perf_matrix.py [OUT.jsonl]: one line per chain, then a trailer that says which library was measured and for how long
+    import hashlib
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    t_start = time.time()
     for c in CASES:
-        print(json.dumps(run(*c)), flush=True)
+        line = json.dumps(run(*c))
+        print(line, flush=True)
+        if out:
+            out.write(line + "\n"); out.flush()
+    lib = F.ratelib.lib_path()
+    trailer = {"trailer": True, "wall_s": round(time.time() - t_start, 1), "device": torch.cuda.get_device_name(0),
+               "lib_sha1": hashlib.sha1(open(lib, "rb").read()).hexdigest()[:12]}
+    print(json.dumps(trailer), flush=True)
+    if out:
+        out.write(json.dumps(trailer) + "\n"); out.close()
