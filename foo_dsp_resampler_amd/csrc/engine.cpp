@@ -44,6 +44,7 @@ const Knobs &knobs()
     r.no_mfma = on("RSMP_NO_MFMA");
     r.no_polymf = on("RSMP_NO_POLYMF");
     r.no_fast = on("RSMP_NO_FAST");
+    r.no_split = on("RSMP_NO_SPLIT");
     r.no_dftx = on("RSMP_NO_DFTX");
     r.no_polyi = on("RSMP_NO_POLYI");
     r.no_polycoop = on("RSMP_NO_POLYCOOP");
@@ -302,12 +303,58 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       const long long a0 = at0 + (long long)(G * m) * pstep, a1 = at0 + (long long)std::min(G * m + G - 1, p.L - 1) * pstep;
       dmax = std::max(dmax, int(a1 / p.L - a0 / p.L));
     }
-    const int threads = f.N / 16;
     const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
-    if (NG > threads || !fused_shape_supported(log2n, log2p, p.n, p.n + dmax, max_seam)) continue;
+    // Blocks too long for one workgroup (8192 / 16384 points): the sub-blocked form of the lean kernel, for the chains it
+    // covers -- x2 stage first in the chain (float frames in), even channel count, the polyphase stage feeding a further
+    // stage (fp64 ring out), matrix-pipe tiles.  There is no generic kernel behind it, so everything is decided here.
+    int split_nsub = 0, split_vs = 0;
+    {
+      const int V = f.N - (f.num_taps - 1), Pref = f.N / 2;
+      int d4 = 0;
+      for (int rb = 0; rb < p.L; rb += 4) {
+        const long long a0 = at0 + (long long)rb * pstep, a1 = at0 + (long long)std::min(rb + 3, p.L - 1) * pstep;
+        d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
+      }
+      const int KS = std::max(7, (p.n + d4 + 3) / 4);
+      if (i == 0 && i + 2 < ns && d.L == 2 && d.remL0 == 0 && !(nch_ & 1) && !(V & 1) && p.L >= 64 && p.n <= 32 && max_seam <= 64 &&
+          !kn.no_fuse && !kn.no_mfma && fused_split_supported(log2n, d.L, KS)) {
+        // the longest sub-block the component transforms leave valid (and the LDS image holds), then an even split
+        const int vmax = std::min(kSplitVsMax, (2 * 4096 - (f.num_taps - 1)) & ~1);
+        if (vmax >= 1024) {
+          split_nsub = (V + vmax - 1) / vmax;
+          split_vs = (((V + split_nsub - 1) / split_nsub) + 1) & ~1;
+          if ((split_nsub - 1) * split_vs >= V) split_nsub = 0; // (cannot happen for V >> nsub)
+          for (int k = 0; k < split_nsub; ++k) {
+            const SubBlock sb = sub_block(k, V, split_vs, Pref);
+            if ((sb.len & 1) || sb.len < 2 * p.n || 2 * sb.shift + sb.len + (f.num_taps - 1) > 8192) split_nsub = 0;
+          }
+        }
+      }
+    }
+    const bool split = split_nsub > 0;
+    const int threads = split ? 256 : f.N / 16;
+    if (!split && (NG > threads || !fused_shape_supported(log2n, log2p, p.n, p.n + dmax, max_seam))) continue;
     if (kn.no_fuse) continue;
     Fuse &fu = fuse_[i];
     fu.on = true;
+    fu.nsub = split_nsub;
+    fu.Vs = split_vs;
+    if (split) { // G_r = DFT_4096(L * h_placed[2 j + r]) / 4096 with h placed at -(taps - 1) .. 0 mod 8192: the block's two components
+      if (!twiddles(12)) return kNoMem;
+      std::vector<double2> Gs(size_t(2) * 4096);
+      for (int r = 0; r < 2; ++r) {
+        std::vector<cplx> g(4096);
+        for (int i2 = 0; i2 < f.num_taps; ++i2) {
+          const int m = (i2 + 8192 - f.num_taps + 1) & 8191;
+          if ((m & 1) == r) g[m >> 1] = f.taps[i2] * d.L;
+        }
+        fft_inplace(g, -1);
+        for (int k = 0; k < 4096; ++k) Gs[size_t(r) * 4096 + k] = make_double2(g[k].real() / 4096, g[k].imag() / 4096);
+      }
+      void *dg = nullptr;
+      if ((rc = upload(Gs.data(), Gs.size() * sizeof(double2), &dg)) != kOk) return rc;
+      fu.Gs = static_cast<double2 *>(dg);
+    }
     fu.span = p.n + dmax;
     fu.NG = NG;
     fu.KC = threads / NG;
@@ -325,7 +372,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     // periods a block can touch: ceil(outputs per block / L) + 1; chunk length fixed from it
     const int Kmax = int(((long long)V * p.L / pstep + p.L - 1) / p.L) + 2;
     fu.kper = (Kmax + fu.KC - 1) / fu.KC;
-    { // coefficient tiles, one per thread of the fused kernel: tile[mm][g] = row(phase of residue G*m+g)[mm - d_g]
+    if (!split) { // coefficient tiles, one per thread of the fused kernel: tile[mm][g] = row(phase of residue G*m+g)[mm - d_g]
       std::vector<double> tiles(size_t(32) * G * threads, 0.0);
       for (int t = 0; t < threads; ++t) {
         const int m = t % NG, kc = t / NG;
@@ -366,7 +413,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
           for (int j2 = j1 + 1; j2 < 4; ++j2)
             if (((j2 - j1) * pstep) % 16 == 0) lanes_spread = false;
       const bool rounds_ok = (qb_max - qb_min) + 4 * KS + 4 <= (kFusedSA - kFusedSB0) * 256 + 32 && Kmax <= 32 && p.L >= 64 && lanes_spread;
-      if (!kn.no_mfma && fused_mfma_supported(log2n, log2p, KS) && rounds_ok) {
+      if (split || (!kn.no_mfma && fused_mfma_supported(log2n, log2p, KS) && rounds_ok)) { // (split: one image, no rounds to fit)
         std::vector<double> am(size_t(NGRP) * KS * 64, 0.0);
         for (int g = 0; g < NGRP; ++g)
           for (int s = 0; s < KS; ++s)
@@ -418,7 +465,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         fu.qtab = static_cast<int *>(dq);
       }
     }
-    const size_t per_launch = size_t(fu.blk_cap - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
+    const size_t per_launch = size_t(fu.blk_cap / std::max(1, fu.nsub) - 2) * size_t((V - d.remL0 + d.L - 1) / d.L);
     // frames of chain input per launch: divide by the rate of everything ahead of the dft stage
     double ahead = 1;
     for (int k = 0; k < i; ++k) ahead *= plan_.stages[k].kind == StageKind::Half ? 0.5 : plan_.stages[k].out_in_ratio;
@@ -669,6 +716,7 @@ Engine::~Engine()
     if (f.cfm) (void)hipFree(f.cfm);
     if (f.qtab) (void)hipFree(f.qtab);
     if (f.cfm2) (void)hipFree(f.cfm2);
+    if (f.Gs) (void)hipFree(f.Gs);
     if (f.blk_dev) (void)hipFree(f.blk_dev);
   }
   for (BigDft &b : big_) {
@@ -895,6 +943,8 @@ int Engine::advance_dft(Pass &ps, int i)
     a.in_limit = 0x7fffffffffffffffLL;
     a.clip_lo = -0x7fffffffffffffffLL;
     a.clip_hi = 0x7fffffffffffffffLL;
+    a.nsub = a.Vs = a.Pref = 0;
+    a.Bref0 = 0;
     if (big) {
       const BigDft &bg = big_[i];
       BigDftArgs ba;
@@ -1009,7 +1059,9 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
     fa.KS = fu.KS;
     fa.dbg = dbg_;
     fa.stamps = stamps_;
-    if (pend.nblocks > fu.blk_cap) return kInternal;
+    const bool split = fu.nsub > 0;
+    const int ntab = split ? pend.nblocks * fu.nsub : pend.nblocks; // table entries = workgroups per pair: blocks, or sub-blocks
+    if (ntab > fu.blk_cap) return kInternal;
     FusedPrepArgs pa; // output bookkeeping of each block (closed forms in kernels.hpp), evaluated on the device
     pa.b_offset = fa.b_offset;
     pa.B0 = pend.B0;
@@ -1018,15 +1070,18 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
     pa.polyL = sp.L;
     pa.step = int(step);
     pa.n = sp.n;
-    pa.nblocks = pend.nblocks;
-    pa.two_round = fu.cfm != nullptr;
+    pa.nblocks = ntab;
+    pa.nsub = fu.nsub;
+    pa.Vs = fu.Vs;
+    pa.two_round = fu.cfm != nullptr && !split;
     pa.KS = fu.KS;
     pa.qb_max = fu.qb_max;
     pa.qb_min = fu.qb_min;
     pa.clip_lo = 0;
     pa.clip_hi = 0x7fffffffffffffffLL;
-    for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
-      if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
+    if (!split)
+      for (int k : {0, pend.nblocks - 1}) // same closed forms on the host: bounds the kernels rely on
+        if (fused_block_info(pa, k).K > (fu.cfm ? 32 : fu.KC * fu.kper)) return kInternal;
     // side stream for the seam kernel only when nothing downstream in this pass reads the seam outputs (poly is the last stage)
     // ... and only when another slab of this push follows: seam(k) then runs beside fused(k+1).  Behind the LAST fused
     // launch of a push the side stream has nothing to overlap with but the small carry copy, and the two cross-queue
@@ -1049,6 +1104,39 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
     // fp64 rings on either side) to the generic one.  At most three launches: generic head, lean middle, generic tail.
     int f0 = 0, f1 = 0;
     FastIo io = {};
+    if (split) {
+      // Sub-blocked form: ONE launch of nblocks * nsub workgroups per channel pair.  Every sub-block's 4096-frame window lies
+      // inside its block's own input span, i.e. in the caller's buffer or, below it, in fifo 0's ring; outputs go to the next
+      // fifo's fp64 ring at any position.  (Decided when the handle was opened: first stage, even channels, not the last stage.)
+      if (!s32 || dst_f32 || (nch_ & 1) || !ein.ptr || (ein.stride_floats & 1)) return kInternal;
+      io.in = ein.ptr;
+      io.in_ring = static_cast<const float *>(rings_[0].buf);
+      io.in_ring_mask = rings_[0].cap - 1;
+      io.in_ring_stream_stride = rings_[0].cap * nch_;
+      io.in_abs0 = ein.begin;
+      io.in_stream_stride = ein.stride_floats;
+      io.nch = nch_;
+      io.in_unaligned = (reinterpret_cast<uintptr_t>(ein.ptr) & 7) ? 1 : 0;
+      io.out64 = static_cast<double *>(rings_[i + 1].buf);
+      io.out64_mask = rings_[i + 1].cap - 1;
+      io.out64_chan_stride = rings_[i + 1].cap;
+      FusedArgs fr = fa;
+      fr.d.G = fu.Gs;
+      fr.d.tw_fwd = fr.d.tw_inv = twiddles(12);
+      if (!fr.d.tw_fwd) return kNoMem;
+      fr.d.nsub = fu.nsub;
+      fr.d.Vs = fu.Vs;
+      fr.d.Pref = 1 << pend_log2p;
+      fr.d.Bref0 = pend.B0;
+      fr.d.B0 = pend.B0 * fu.nsub;
+      fr.d.nblocks = ntab;
+      fa = fr; // seam_kernel below: sub-block indices, same table
+      const int pi = prof_begin(true);
+      const char *kn = nullptr;
+      HIP_TRY(launch_fused_split(fr, io, stream_, &kn));
+      prof_name(pi, kn);
+      prof_end(pi);
+    } else
     if (fu.cfm && s32 && dst_f32 && !(nch_ & 1) && ein.ptr && eout.ptr && fused_fast_supported(pend_log2n, pend_log2p, fu.KS) &&
         !(reinterpret_cast<uintptr_t>(ein.ptr) & 7) && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7) && !(ein.stride_floats & 1) &&
         !(eout.stride_floats & 1)) {
@@ -1111,9 +1199,11 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
       prof_end(pi);
       return kOk;
     };
-    { int rl = launch_range(0, f0, false); if (rl) return rl; }
-    { int rl = launch_range(f0, f1, true); if (rl) return rl; }
-    { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
+    if (!split) {
+      { int rl = launch_range(0, f0, false); if (rl) return rl; }
+      { int rl = launch_range(f0, f1, true); if (rl) return rl; }
+      { int rl = launch_range(f1, pend.nblocks, false); if (rl) return rl; }
+    }
     if (!seam_on_side) {
       { int rcj = join_side(); if (rcj) return rcj; } // (a seam kernel of an earlier launch of this push may still be on the side stream)
       const int ps = prof_begin(false, "rsmp::seam_kernel");
@@ -1151,6 +1241,7 @@ int Engine::launch_polymf_stage(Pass &ps, int i, long long count, long long step
     pa.n = 1;
     pa.nblocks = int(std::min<long long>(pm.blk_cap, t_end - t0));
     pa.two_round = 0;
+    pa.nsub = pa.Vs = 0;
     pa.KS = pm.KS;
     pa.qb_max = 0;
     pa.qb_min = 0;

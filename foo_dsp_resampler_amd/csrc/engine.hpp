@@ -168,7 +168,9 @@ private:
   // fused dft->vpoly0 path
   struct Fuse { bool on = false; int span = 0, NG = 0, KC = 0, kper = 0; double *seam = nullptr; double *cft = nullptr; int slots = 0;
                 double *cfm = nullptr; int NGRP = 0, KS = 0, qb_max = 0, qb_min = 0; int *qtab = nullptr; double2 *cfm2 = nullptr;
-                FusedBlock *blk_dev = nullptr; int blk_cap = 0; };
+                FusedBlock *blk_dev = nullptr; int blk_cap = 0;
+                // sub-blocked form (fused_fast_kernel<.., SPLIT>): nsub sub-blocks of Vs samples per block, component spectra
+                int nsub = 0, Vs = 0; double2 *Gs = nullptr; };
   std::vector<Fuse> fuse_;            // indexed by the dft stage
   // standalone matrix-pipe polyphase stage (polymf.hip), indexed by the poly stage
   struct PolyMf { double *cfm = nullptr; int *qtab = nullptr; FusedBlock *blk = nullptr; int KS = 0, NGRP = 0, Vt = 0, blk_cap = 0; };

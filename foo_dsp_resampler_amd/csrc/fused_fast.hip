@@ -81,9 +81,18 @@ constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 
 // OUT64: the outputs go to the planar fp64 ring of the next stage's fifo (absolute index & mask: a ring wrap costs nothing)
 // instead of interleaved float frames -- chains like 44.1k->192k, whose x2 -> 80/147 pair feeds an x4 stage.
-template <int LOG2P, int KS, bool OUT64>
-__global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
+//
+// SPLIT (LOG2P = 12, OUT64): the sub-blocked form for x2 stages whose blocks (8192 or 16384 points) do not fit a workgroup.
+// A block of the reference is nsub workgroups; each computes `len` of the block's valid samples from a 4096-point window of
+// the block's inputs: y[2m + r] = IDFT_4096(DFT_4096(x) * G_r)[m], r = 0, 1 -- the block's two polyphase components, the same
+// linear convolution as the reference's one long transform, in a different fp64 summation order.  One forward and two inverse
+// transforms; component 0 waits in registers while component 1 is computed (256-VGPR budget: two workgroups per CU), then
+// both go to ONE LDS image of the whole sub-block and the polyphase stage runs as a single round.  B counts sub-blocks, so the
+// seam ring, the block table and seam_kernel work on sub-blocks exactly as they do on blocks.
+template <int LOG2P, int KS, bool OUT64, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
 {
+  static_assert(!SPLIT || (LOG2P == 12 && OUT64), "sub-blocked form: 4096-point components, fp64 ring behind the polyphase stage");
   constexpr int LOG2N = 12, N = 1 << LOG2N, P = 1 << LOG2P;
   constexpr int T = N / 16, TF = P / 16;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -94,10 +103,17 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   if (!item_map(blockIdx.x, a.d.nblocks, npairs, a.d.hp, bl, pair)) return; // uniform
   const long long B = a.d.B0 + bl;
   const int hp = io.nch >> 1, strm = pair / hp, pin = pair - strm * hp;
+  SubBlock sb = {0, 0, 0, 0};
+  long long e0_split = 0;
+  if constexpr (SPLIT) { // (the launch starts at sub-block 0 of reference block Bref0)
+    const int kr = bl / a.d.nsub;
+    sb = sub_block(bl - kr * a.d.nsub, a.d.V, a.d.Vs, a.d.Pref);
+    e0_split = (a.d.Bref0 + kr) * a.d.q + sb.win;
+  }
 #if defined(RSMP_EXPERIMENTS) && defined(RSMP_VCONST) // what a block length known at compile time would buy (553-tap filters: 3544)
   const int V = RSMP_VCONST;
 #else
-  const int V = a.d.V;
+  const int V = SPLIT ? sb.len : a.d.V;
 #endif
   const bool fwd_active = tid < TF;
   const double2 *__restrict__ Gp = a.d.G;
@@ -129,16 +145,27 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   constexpr int NLD = FWD8 ? 8 : 16, TL = FWD8 ? T : TF; // points per loading thread, loading threads
   c64 v[16];
   c64 u8[8];
+  c64 z0[SPLIT ? 16 : 1]; // sub-blocked form: component 0 of the block (samples 2m), component 1 ends up in `v`
   constexpr bool PRETW = FWD8 && RSMP_FWD_PRETW;
   double2 wf[PRETW ? fft8_tw_regs(LOG2P) : 1];
   if constexpr (PRETW) fft8_tw_load<LOG2P>(wf, tid, a.d.tw_fwd8); // in flight together with the input loads below
   {
-    const long long e0 = B * a.d.q;
+    const long long e0 = SPLIT ? e0_split : B * a.d.q;
     const bool ld_active = (FWD8 || fwd_active) && !(RSMP_EXP_SKIP & 256);
     if (RSMP_EXP_SKIP & 256) {
 #pragma unroll
       for (int s = 0; s < NLD; ++s) (FWD8 ? u8[s & 7] : v[s]) = {1e-3 * tid, 1e-3 * s};
     }
+    if (SPLIT && io.in_unaligned) { // (uniform) a caller's buffer that is only 4-byte aligned: the sub-blocked form has no generic
+      // kernel to hand such blocks to, so it reads the two channels separately
+      const float *pe = io.in + strm * io.in_stream_stride + 2 * pin, *pr = io.in_ring + strm * io.in_ring_stream_stride + 2 * pin;
+#pragma unroll
+      for (int s = 0; s < NLD; ++s) {
+        const long long e = e0 + tid + s * TL;
+        const float *f = e >= io.in_abs0 ? pe + (e - io.in_abs0) * io.nch : pr + (e & io.in_ring_mask) * io.nch;
+        v[s] = {(double)f[0], (double)f[1]};
+      }
+    } else
     if (e0 >= io.in_abs0) { // uniform: the whole block lies in the caller's buffer
       const float2 *p2 = reinterpret_cast<const float2 *>(io.in + strm * io.in_stream_stride + (e0 - io.in_abs0) * io.nch + 2 * pin);
       if (ld_active) {
@@ -214,6 +241,26 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = cmul(z[s & 7], c64{g[s].x, g[s].y});
     __syncthreads();
+  } else if constexpr (SPLIT) {
+    // X = DFT_4096 of the window stays in `xs` for both components; component 0's samples wait in `z0`
+    c64 xs[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      xs[s] = v[s];
+      const double2 g = load_g(Gp + tid + s * T);
+      v[s] = cmul(xs[s], c64{g.x, g.y});
+    }
+    fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
+    double2 g1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g1[s] = load_g(Gp + N + tid + s * T);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      z0[s] = v[s];
+      v[s] = cmul(xs[s], c64{g1[s].x, g1[s].y});
+    }
+    __syncthreads(); // the second inverse transform's exchange reuses the LDS the first one just read
+    fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
   } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -223,7 +270,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   }
   }
   RSMP_STAMP(2)
-  if constexpr (!(RSMP_EXP_SKIP & 2)) fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
+  if constexpr (!(RSMP_EXP_SKIP & 2) && !SPLIT) fft_regs<LOG2N, +1, 2, RSMP_PFI, RSMP_TWGEN != 0>(v, tid, true, a.d.tw_inv, lds);
   RSMP_STAMP(3)
 
   // ---------------------------------------------------------------- stage-1 samples -> LDS (round A) and seam ring
@@ -236,6 +283,23 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
     // (store_tail), where it is 23 consecutive elements -- out of registers it took per-lane range tests and a pair of
     // conditional global stores in every one of the 16 unrolled slots (V is a run-time value): ~300 scalar and ~150 vector
     // instructions per wave for 46 doubles.
+    if constexpr (SPLIT) {
+      __syncthreads(); // the image overlays the exchange area of the last transform
+      // element m of component r is sample 2 (m - shift) + r of the sub-block; the whole sub-block fits the image
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int n = 2 * (tid + s * T - sb.shift);
+        if (n >= 0 && n < V) { // (V is even)
+          smp[n] = make_double2(z0[s].x, z0[s].y);
+          smp[n + 1] = make_double2(v[s].x, v[s].y);
+        }
+      }
+      if (tid < kPad) {
+        smp[tid - kPad] = make_double2(0.0, 0.0);
+        smp[V + tid] = make_double2(0.0, 0.0);
+      }
+      (void)seamA; (void)seamB;
+    } else {
 #pragma unroll
     for (int s = 0; s <= kSA; ++s) {
       const int n = tid + s * T;
@@ -252,8 +316,17 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       smp[tid - kPad] = make_double2(0.0, 0.0);
       if (V < kSA * T + kPad) smp[V + tid] = make_double2(0.0, 0.0);
     }
+    }
   }
   __syncthreads();
+  if constexpr (SPLIT) { // the head goes to the seam ring from the image (its register slot depends on the sub-block's shift)
+    if (tid < nm1) {
+      const int slot = (int)(B & a.seam_mask);
+      const double2 t = smp[tid];
+      a.seam[((long long)(slot * (a.d.C + 1) + ca) * 2) * 32 + tid] = t.x;
+      a.seam[((long long)(slot * (a.d.C + 1) + cb) * 2) * 32 + tid] = t.y;
+    }
+  }
   // the block's last n-1 samples -> seam ring, read back from whichever LDS image holds them (element 0 of `img` = sample n0)
   const int tail0 = V - nm1;
   auto store_tail = [&](const double2 *img, int n0) {
@@ -264,7 +337,7 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
       a.seam[((long long)(slot * (a.d.C + 1) + cb) * 2 + 1) * 32 + tid] = t.y;
     }
   };
-  const bool tail_in_b = tail0 >= kSB0 * T; // uniform: else the whole tail lies inside the first image (V <= kSB0 * T + n - 1)
+  const bool tail_in_b = !SPLIT && tail0 >= kSB0 * T; // uniform: else the whole tail lies inside the first image (V <= kSB0 * T + n - 1)
   if (!tail_in_b) store_tail(smp, 0);
   RSMP_STAMP(4)
 
@@ -444,6 +517,10 @@ __global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs 
   if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
   if (RSMP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   // round A: periods whose windows end inside the samples written above
+  if constexpr (SPLIT) {
+    if (run) poly_round(0, fb.K, smp, -kPad, V + kPad - 4 * KS); // one round over the whole image
+    return;
+  }
   if (run) poly_round(0, fb.KA, smp, -kPad, min(V, kSA * T) + kPad - 4 * KS);
   RSMP_STAMP(6)
   __syncthreads();
@@ -480,6 +557,51 @@ template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const F
   dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(N / 16);
   hipLaunchKernelGGL((fused_fast_kernel<LOG2P, KS, OUT64>), grid, block, lds_bytes, st, b, io);
   return hipGetLastError();
+}
+
+template <int KS> static hipError_t launch_split_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
+{
+  // the image of the longest sub-block, or the exchange area of the transforms, whichever is larger: <= 80 KB, two per CU
+  const size_t lds_max = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + kSplitVsMax + kPad) * 16);
+  const size_t lds_bytes = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + a.d.Vs + kPad) * 16);
+  static DynLdsOnce attr;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_fast_kernel<12, KS, true, true>), int(lds_max)); e != hipSuccess) return e;
+  FusedArgs b = a;
+  b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
+  dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(256);
+  hipLaunchKernelGGL((fused_fast_kernel<12, KS, true, true>), grid, block, lds_bytes, st, b, io);
+  return hipGetLastError();
+}
+
+bool fused_split_supported(int log2n, int L, int ksteps)
+{
+  return !knobs().no_fast && !knobs().no_split && L == 2 && (log2n == 13 || log2n == 14) && ksteps >= 7 && ksteps <= 9;
+}
+
+hipError_t launch_fused_split(const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
+{
+  // what the kernel's indexing assumes, checked where the launch is made
+  if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || a.d.Vs > kSplitVsMax || (a.d.V & 1) || a.d.nblocks % a.d.nsub || !io.out64 ||
+      (a.d.Pref != 4096 && a.d.Pref != 8192) || a.d.nsub * a.d.Vs < a.d.V || (a.d.nsub - 1) * a.d.Vs >= a.d.V || (io.nch & 1))
+    return hipErrorInvalidValue;
+  for (int i = 0; i < a.d.nsub; ++i) { // every sub-block's samples must be free of the component transforms' wrap-around
+    const SubBlock sb = sub_block(i, a.d.V, a.d.Vs, a.d.Pref);
+    const int ov = 2 * a.d.Pref - a.d.V; // taps - 1
+    if (sb.win < 0 || sb.shift < 0 || sb.shift + sb.len / 2 + (ov + 1) / 2 > 4096 || (sb.len & 1) || sb.win + 4096 > a.d.Pref) return hipErrorInvalidValue;
+  }
+  if (a.KS == 7) {
+    if (kname) *kname = "rsmp::fused_fast_kernel<12, 7, true, true>";
+    return launch_split_t<7>(a, io, st);
+  }
+  if (a.KS == 8) {
+    if (kname) *kname = "rsmp::fused_fast_kernel<12, 8, true, true>";
+    return launch_split_t<8>(a, io, st);
+  }
+  if (a.KS == 9) { // (80 phases at step 147: the windows of a 4-residue block spread over 34 samples)
+    if (kname) *kname = "rsmp::fused_fast_kernel<12, 9, true, true>";
+    return launch_split_t<9>(a, io, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 bool fused_fast_supported(int log2n, int log2p, int ksteps)

@@ -74,7 +74,28 @@ struct DftArgs {
   int hp;                // channel pairs per interleaved float frame whose workgroups are co-located (item_map); 0/1 = none
   long long in_limit;    // input items at absolute index >= in_limit read as zero (unused by the engine: always +inf)
   long long clip_lo, clip_hi; // only stage outputs with absolute index in [clip_lo, clip_hi) are stored (always everything)
+  // Sub-blocked fused launch (fused_fast_kernel<.., SPLIT>, fused_fast.hip): every block of the reference is computed as
+  // `nsub` sub-blocks of `Vs` valid samples (the last one shorter) on 4096-point component transforms; B0 / nblocks then
+  // count SUB-blocks (B0 = Bref0 * nsub) and G holds the two component spectra.  nsub = 0: not sub-blocked.
+  int nsub, Vs;
+  int Pref;              // inputs a reference block spans (N / L)
+  long long Bref0;       // first reference block of the launch
 };
+
+// Geometry of sub-block `i` of a reference block with V valid samples out of N/L = `Pref` inputs (x2 chains): its `len` valid
+// samples start `off` samples into the block's valid range; its 4096-point input window starts `win` inputs into the block's
+// input span -- as late as the samples allow, but never so late that it would reach past the block's own inputs -- and its
+// first valid sample is element `shift` of each component transform's output.
+struct SubBlock { int off, len, win, shift; };
+__host__ __device__ inline SubBlock sub_block(int i, int V, int Vs, int Pref)
+{
+  SubBlock s;
+  s.off = i * Vs;
+  s.len = V - s.off < Vs ? V - s.off : Vs;
+  s.win = (s.off >> 1) < Pref - 4096 ? (s.off >> 1) : Pref - 4096;
+  s.shift = (s.off >> 1) - s.win;
+  return s;
+}
 
 // number of channel pairs (= workgroups per block) of a launch, see pair_channels (fifo_device.hpp)
 __host__ __device__ inline int pair_count(int C, int nchs) { return nchs > 0 ? (C / nchs) * ((nchs + 1) >> 1) : (C + 1) >> 1; }
@@ -128,11 +149,18 @@ struct FusedPrepArgs {
   int two_round, KS, qb_max;   // matrix-pipe variant: split of the periods over its two LDS images
   int qb_min;                  // (smallest / largest window start of a 4-residue block, relative to its period)
   long long clip_lo, clip_hi;  // only outputs with index in [clip_lo, clip_hi) belong to this launch (standalone stage)
+  int nsub, Vs;                // sub-blocked launch (DftArgs::nsub): entry k is sub-block k % nsub of reference block B0 + k / nsub
 };
 __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, int k)
 {
-  const long long b0 = p.b_offset + (p.B0 + k) * (long long)p.V;
-  const long long nlo = b0 * p.polyL - p.at0, nhi = (b0 + p.V - p.n + 1) * p.polyL - p.at0;
+  long long b0 = p.b_offset + (p.B0 + k) * (long long)p.V;
+  int V = p.V;
+  if (p.nsub > 0) {
+    const int kr = k / p.nsub, i = k - kr * p.nsub;
+    b0 = p.b_offset + (p.B0 + kr) * (long long)p.V + (long long)i * p.Vs;
+    V = p.V - i * p.Vs < p.Vs ? p.V - i * p.Vs : p.Vs;
+  }
+  const long long nlo = b0 * p.polyL - p.at0, nhi = (b0 + V - p.n + 1) * p.polyL - p.at0;
   long long ilo = nlo <= 0 ? 0 : (nlo + p.step - 1) / p.step, ihi = nhi <= 0 ? 0 : (nhi + p.step - 1) / p.step;
   if (ilo < p.clip_lo) ilo = p.clip_lo;
   if (ihi > p.clip_hi) ihi = p.clip_hi;
@@ -152,7 +180,7 @@ __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, i
     fb.seam_q0 = int(q0 - (b0 - (p.n - 1)));
     fb.seam_ph0 = int(a0 - q0 * p.polyL);
   }
-  if (p.two_round && p.V > kFusedSA * 256) { // periods whose (padded) windows end inside the first LDS image
+  if (p.two_round && V > kFusedSA * 256) { // periods whose (padded) windows end inside the first LDS image
     const int a_hi = kFusedSA * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
     const int ka = num < 0 ? 0 : num / p.step + 1;
     fb.KA = ka < fb.K ? ka : fb.K;
@@ -197,12 +225,17 @@ struct FastIo {
   long long in_abs0, out_abs0;
   long long in_stream_stride, out_stream_stride; // floats between streams
   int nch;                    // channels per stream (even)
+  int in_unaligned;           // sub-blocked form only: `in` is not 8-byte aligned (channels read one float at a time)
   // OUT64 instances (the polyphase stage feeds another stage): planar fp64 ring of the destination fifo instead of `out`
   double *out64;              // ring of channel 0
   long long out64_mask, out64_chan_stride; // items - 1, items between channels
 };
 bool fused_fast_supported(int log2n, int log2p, int ksteps);
 hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
+// the sub-blocked form: x2 stages with 8192- or 16384-point blocks -> vpoly0 -> fp64 ring of a further stage
+constexpr int kSplitVsMax = 5056; // valid samples of a sub-block: (32 + Vs + 32) 16-byte LDS elements, two workgroups per CU
+bool fused_split_supported(int log2n, int L, int ksteps);
+hipError_t launch_fused_split(const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
 
 struct PolyArgs {
   const double *tab;     // [phase][tap][order+1]
