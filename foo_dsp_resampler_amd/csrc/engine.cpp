@@ -305,8 +305,9 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     }
     const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
     // Blocks too long for one workgroup (8192 / 16384 points): the sub-blocked form of the lean kernel, for the chains it
-    // covers -- x2 stage first in the chain (float frames in), even channel count, the polyphase stage feeding a further
-    // stage (fp64 ring out), matrix-pipe tiles.  There is no generic kernel behind it, so everything is decided here.
+    // covers -- x2 stage first in the chain (float frames in), even channel count, matrix-pipe tiles; the polyphase stage
+    // either last (float frames out) or feeding a further stage (fp64 ring out).  There is no generic kernel behind it, so
+    // everything is decided here.
     int split_nsub = 0, split_vs = 0;
     {
       const int V = f.N - (f.num_taps - 1), Pref = f.N / 2;
@@ -316,7 +317,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
       }
       const int KS = std::max(7, (p.n + d4 + 3) / 4);
-      if (i == 0 && i + 2 < ns && d.L == 2 && d.remL0 == 0 && !(nch_ & 1) && !(V & 1) && p.L >= 64 && p.n <= 32 && max_seam <= 64 &&
+      if (i == 0 && d.L == 2 && d.remL0 == 0 && !(nch_ & 1) && !(V & 1) && p.L >= 64 && p.n <= 32 && max_seam <= 64 &&
           !kn.no_fuse && !kn.no_mfma && fused_split_supported(log2n, d.L, KS)) {
         // the longest sub-block the component transforms leave valid (and the LDS image holds), then an even split
         const int vmax = std::min(kSplitVsMax, (2 * 4096 - (f.num_taps - 1)) & ~1);
@@ -357,7 +358,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     }
     fu.span = p.n + dmax;
     fu.NG = NG;
-    fu.KC = threads / NG;
+    fu.KC = split ? 1 : threads / NG; // (vector variant's thread map: unused by the sub-blocked form, whose NG may exceed 256)
     // blocks per launch: as many as a seam ring of at most 1280 MB allows (0.4 % of the card; round 2's 320 MB cut a 963 379-frame
     // push of 256 stereo streams into three launches, each with its own prep / seam kernels and gaps; two launches worth of slots: seam(k) still
     // reads its slots while fused(k+1) fills the next ones)
@@ -1108,7 +1109,7 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
       // Sub-blocked form: ONE launch of nblocks * nsub workgroups per channel pair.  Every sub-block's 4096-frame window lies
       // inside its block's own input span, i.e. in the caller's buffer or, below it, in fifo 0's ring; outputs go to the next
       // fifo's fp64 ring at any position.  (Decided when the handle was opened: first stage, even channels, not the last stage.)
-      if (!s32 || dst_f32 || (nch_ & 1) || !ein.ptr || (ein.stride_floats & 1)) return kInternal;
+      if (!s32 || (nch_ & 1) || !ein.ptr || (ein.stride_floats & 1)) return kInternal;
       io.in = ein.ptr;
       io.in_ring = static_cast<const float *>(rings_[0].buf);
       io.in_ring_mask = rings_[0].cap - 1;
@@ -1117,9 +1118,28 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
       io.in_stream_stride = ein.stride_floats;
       io.nch = nch_;
       io.in_unaligned = (reinterpret_cast<uintptr_t>(ein.ptr) & 7) ? 1 : 0;
-      io.out64 = static_cast<double *>(rings_[i + 1].buf);
-      io.out64_mask = rings_[i + 1].cap - 1;
-      io.out64_chan_stride = rings_[i + 1].cap;
+      int omode = 1;
+      if (!dst_f32) {
+        io.out64 = static_cast<double *>(rings_[i + 1].buf);
+        io.out64_mask = rings_[i + 1].cap - 1;
+        io.out64_chan_stride = rings_[i + 1].cap;
+      } else {
+        // float frames out: straight into the caller's buffer when every output of this launch lies inside it (a flow / a
+        // mirrored push), else output by output wherever the fifo has it (RR_push: everything into the ring)
+        const bool ext_ok = eout.ptr && !(eout.stride_floats & 1);
+        const bool all_inside = ext_ok && wro >= eout.begin && wro + count <= eout.end;
+        omode = (all_inside && !(reinterpret_cast<uintptr_t>(eout.ptr) & 7)) ? 0 : 2;
+        io.out = ext_ok ? eout.ptr : nullptr;
+        io.out_abs0 = ext_ok ? eout.begin : 0;
+        io.out_end = ext_ok ? eout.end : 0; // (empty range: every output goes to the ring)
+        io.out_stream_stride = ext_ok ? eout.stride_floats : 0;
+        io.out_unaligned = (ext_ok && (reinterpret_cast<uintptr_t>(eout.ptr) & 7)) ? 1 : 0;
+        io.out_ring = static_cast<float *>(rings_[i + 1].buf);
+        io.out_ring_mask = rings_[i + 1].cap - 1;
+        io.out_ring_stream_stride = rings_[i + 1].cap * nch_;
+        if (eout.ptr && !ext_ok) return kInternal; // (an odd frame stride with an even channel count cannot happen)
+        if (omode == 2 && !io.out_ring) return kInternal;
+      }
       FusedArgs fr = fa;
       fr.d.G = fu.Gs;
       fr.d.tw_fwd = fr.d.tw_inv = twiddles(12);
@@ -1133,7 +1153,7 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
       fa = fr; // seam_kernel below: sub-block indices, same table
       const int pi = prof_begin(true);
       const char *kn = nullptr;
-      HIP_TRY(launch_fused_split(fr, io, stream_, &kn));
+      HIP_TRY(launch_fused_split(omode, fr, io, stream_, &kn));
       prof_name(pi, kn);
       prof_end(pi);
     } else

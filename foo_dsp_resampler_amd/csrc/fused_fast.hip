@@ -82,17 +82,20 @@ constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 // OUT64: the outputs go to the planar fp64 ring of the next stage's fifo (absolute index & mask: a ring wrap costs nothing)
 // instead of interleaved float frames -- chains like 44.1k->192k, whose x2 -> 80/147 pair feeds an x4 stage.
 //
-// SPLIT (LOG2P = 12, OUT64): the sub-blocked form for x2 stages whose blocks (8192 or 16384 points) do not fit a workgroup.
+// SPLIT (LOG2P = 12; kernel name fused_split_kernel<KS, OMODE>): the sub-blocked form for x2 stages whose blocks (8192 or 16384 points) do not fit a workgroup.
 // A block of the reference is nsub workgroups; each computes `len` of the block's valid samples from a 4096-point window of
 // the block's inputs: y[2m + r] = IDFT_4096(DFT_4096(x) * G_r)[m], r = 0, 1 -- the block's two polyphase components, the same
 // linear convolution as the reference's one long transform, in a different fp64 summation order.  One forward and two inverse
 // transforms; component 0 waits in registers while component 1 is computed (256-VGPR budget: two workgroups per CU), then
 // both go to ONE LDS image of the whole sub-block and the polyphase stage runs as a single round.  B counts sub-blocks, so the
 // seam ring, the block table and seam_kernel work on sub-blocks exactly as they do on blocks.
-template <int LOG2P, int KS, bool OUT64, bool SPLIT = false>
-__global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
+// OGEN (sub-blocked form only): float frames out, each output wherever the output fifo has it -- the caller's buffer or the
+// fifo's ring (RR_push without a destination, outputs beyond the caller's capacity): fifo_put for a channel pair.
+template <int LOG2P, int KS, bool OUT64, bool SPLIT, bool OGEN>
+__device__ __forceinline__ void fused_fast_body(const FusedArgs &a, const FastIo &io)
 {
-  static_assert(!SPLIT || (LOG2P == 12 && OUT64), "sub-blocked form: 4096-point components, fp64 ring behind the polyphase stage");
+  static_assert(!SPLIT || LOG2P == 12, "sub-blocked form: 4096-point components");
+  static_assert(!OGEN || (SPLIT && !OUT64), "generic float output exists for the sub-blocked form only");
   constexpr int LOG2N = 12, N = 1 << LOG2N, P = 1 << LOG2P;
   constexpr int T = N / 16, TF = P / 16;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -350,8 +353,12 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kerne
   const int pl = a.polyL, step = a.step;
   const int irel_hi = fb.irel_lo + fb.cnt;
   const int frame_bytes = io.nch * 4;
-  char *const obytes = OUT64 ? nullptr
+  char *const obytes = (OUT64 || OGEN) ? nullptr
                             : reinterpret_cast<char *>(io.out + strm * io.out_stream_stride + (a.out_offset2 + fb.i_lo - io.out_abs0) * io.nch + 2 * pin);
+  // OGEN: absolute index (in the output fifo) of the block's output 0, this pair's slot of a frame in either buffer
+  const long long oabs0 = a.out_offset2 + fb.i_lo;
+  float *const oext = OGEN ? io.out + strm * io.out_stream_stride + 2 * pin : nullptr;
+  float *const oring = OGEN ? io.out_ring + strm * io.out_ring_stream_stride + 2 * pin : nullptr;
   // OUT64: one descriptor per channel over its whole ring; output ib of the block sits at ring slot (o64 + ib) & mask
   const unsigned o64 = OUT64 ? (unsigned)((a.out_offset2 + fb.i_lo) & io.out64_mask) : 0u;
   const unsigned m64 = (unsigned)io.out64_mask;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kerne
 #if RSMP_BUFSTORE
     // raw buffer over this round's outputs [0, cnt) of the block: frame ib at byte ib * frame_bytes, 8 bytes of it are ours
     const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc(obytes, 0, (!OUT64 && cnt > 0) ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(obytes, 0, (!OUT64 && !OGEN && cnt > 0) ? (cnt - 1) * frame_bytes + 8 : 0, 0x00020000);
 #endif
     const int step4 = 4 * step, pl4 = 4 * pl;
     // store offset of a tile = (this lane's part, once per round) + (the tile's part, scalar): one vector add per tile.  Only the
@@ -460,7 +467,17 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kerne
       for (int s = 3; s < KS; ++s) { accA += xc[s].x * 1e-30; accB += cc[s] * 1e-30 + xc[s].y * 1e-30; } // keep the loads alive
 #endif
       const int ib = lane_ib + 16 * g + c * pl4;
-      if constexpr (OUT64) {
+      if constexpr (OGEN) {
+        if ((unsigned)ib < (unsigned)cnt && 16 * g + rloc < pl) {
+          const long long A = oabs0 + ib;
+          float *const p = (A >= io.out_abs0 && A < io.out_end) ? oext + (A - io.out_abs0) * io.nch : oring + (A & io.out_ring_mask) * io.nch;
+          if (io.out_unaligned) { // (uniform) a caller's buffer that is only 4-byte aligned
+            p[0] = (float)accA;
+            p[1] = (float)accB;
+          } else
+            *reinterpret_cast<float2 *>(p) = make_float2((float)accA, (float)accB);
+        }
+      } else if constexpr (OUT64) {
         // (the descriptor spans the ring, so the block's range test is explicit here; lanes that fail it get an offset
         // behind the ring and the hardware drops their stores)
         const bool ok = (unsigned)ib < (unsigned)cnt && 16 * g + rloc < pl;
@@ -544,6 +561,19 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : kFusedWaves) void fused_fast_kerne
 #undef RSMP_STAMP
 }
 
+// (thin kernels around one body, so that the lean kernel keeps the name its profiles are filed under)
+template <int LOG2P, int KS, bool OUT64>
+__global__ __launch_bounds__(256, kFusedWaves) void fused_fast_kernel(FusedArgs a, FastIo io)
+{
+  fused_fast_body<LOG2P, KS, OUT64, false, false>(a, io);
+}
+// OMODE: 0 = float frames straight into the caller's buffer, 1 = the next fifo's fp64 ring, 2 = float frames via the fifo (OGEN)
+template <int KS, int OMODE>
+__global__ __launch_bounds__(256, 2) void fused_split_kernel(FusedArgs a, FastIo io)
+{
+  fused_fast_body<12, KS, OMODE == 1, true, OMODE == 2>(a, io);
+}
+
 template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
   constexpr int N = 4096;
@@ -559,17 +589,17 @@ template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const F
   return hipGetLastError();
 }
 
-template <int KS> static hipError_t launch_split_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
+template <int KS, int OMODE> static hipError_t launch_split_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
   // the image of the longest sub-block, or the exchange area of the transforms, whichever is larger: <= 80 KB, two per CU
   const size_t lds_max = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + kSplitVsMax + kPad) * 16);
   const size_t lds_bytes = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + a.d.Vs + kPad) * 16);
   static DynLdsOnce attr;
-  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_fast_kernel<12, KS, true, true>), int(lds_max)); e != hipSuccess) return e;
+  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_split_kernel<KS, OMODE>), int(lds_max)); e != hipSuccess) return e;
   FusedArgs b = a;
   b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
   dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(256);
-  hipLaunchKernelGGL((fused_fast_kernel<12, KS, true, true>), grid, block, lds_bytes, st, b, io);
+  hipLaunchKernelGGL((fused_split_kernel<KS, OMODE>), grid, block, lds_bytes, st, b, io);
   return hipGetLastError();
 }
 
@@ -578,10 +608,11 @@ bool fused_split_supported(int log2n, int L, int ksteps)
   return !knobs().no_fast && !knobs().no_split && L == 2 && (log2n == 13 || log2n == 14) && ksteps >= 7 && ksteps <= 9;
 }
 
-hipError_t launch_fused_split(const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
+hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
 {
   // what the kernel's indexing assumes, checked where the launch is made
-  if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || a.d.Vs > kSplitVsMax || (a.d.V & 1) || a.d.nblocks % a.d.nsub || !io.out64 ||
+  if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || a.d.Vs > kSplitVsMax || (a.d.V & 1) || a.d.nblocks % a.d.nsub || omode < 0 || omode > 2 ||
+      (omode == 1 ? !io.out64 : omode == 2 ? !io.out_ring : !io.out) ||
       (a.d.Pref != 4096 && a.d.Pref != 8192) || a.d.nsub * a.d.Vs < a.d.V || (a.d.nsub - 1) * a.d.Vs >= a.d.V || (io.nch & 1))
     return hipErrorInvalidValue;
   for (int i = 0; i < a.d.nsub; ++i) { // every sub-block's samples must be free of the component transforms' wrap-around
@@ -589,18 +620,15 @@ hipError_t launch_fused_split(const FusedArgs &a, const FastIo &io, hipStream_t 
     const int ov = 2 * a.d.Pref - a.d.V; // taps - 1
     if (sb.win < 0 || sb.shift < 0 || sb.shift + sb.len / 2 + (ov + 1) / 2 > 4096 || (sb.len & 1) || sb.win + 4096 > a.d.Pref) return hipErrorInvalidValue;
   }
-  if (a.KS == 7) {
-    if (kname) *kname = "rsmp::fused_fast_kernel<12, 7, true, true>";
-    return launch_split_t<7>(a, io, st);
+#define RSMP_SPLIT_CASE(ks, om)                                                        \
+  if (a.KS == ks && omode == om) {                                                     \
+    if (kname) *kname = "rsmp::fused_split_kernel<" #ks ", " #om ">";                  \
+    return launch_split_t<ks, om>(a, io, st);                                          \
   }
-  if (a.KS == 8) {
-    if (kname) *kname = "rsmp::fused_fast_kernel<12, 8, true, true>";
-    return launch_split_t<8>(a, io, st);
-  }
-  if (a.KS == 9) { // (80 phases at step 147: the windows of a 4-residue block spread over 34 samples)
-    if (kname) *kname = "rsmp::fused_fast_kernel<12, 9, true, true>";
-    return launch_split_t<9>(a, io, st);
-  }
+  // (9 k-steps: 80 phases at step 147, the windows of a 4-residue block spread over 34 samples)
+  RSMP_SPLIT_CASE(7, 0) RSMP_SPLIT_CASE(7, 1) RSMP_SPLIT_CASE(7, 2) RSMP_SPLIT_CASE(8, 0) RSMP_SPLIT_CASE(8, 1) RSMP_SPLIT_CASE(8, 2)
+  RSMP_SPLIT_CASE(9, 0) RSMP_SPLIT_CASE(9, 1) RSMP_SPLIT_CASE(9, 2)
+#undef RSMP_SPLIT_CASE
   return hipErrorInvalidValue;
 }
 

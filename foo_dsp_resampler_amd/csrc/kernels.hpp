@@ -226,16 +226,22 @@ struct FastIo {
   long long in_stream_stride, out_stream_stride; // floats between streams
   int nch;                    // channels per stream (even)
   int in_unaligned;           // sub-blocked form only: `in` is not 8-byte aligned (channels read one float at a time)
+  // sub-blocked form, omode 2: frame with absolute index A is in `out` when out_abs0 <= A < out_end, else in the fifo's ring
+  float *out_ring;
+  long long out_ring_mask, out_ring_stream_stride, out_end;
+  int out_unaligned;          // `out` is not 8-byte aligned
   // OUT64 instances (the polyphase stage feeds another stage): planar fp64 ring of the destination fifo instead of `out`
   double *out64;              // ring of channel 0
   long long out64_mask, out64_chan_stride; // items - 1, items between channels
 };
 bool fused_fast_supported(int log2n, int log2p, int ksteps);
 hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
-// the sub-blocked form: x2 stages with 8192- or 16384-point blocks -> vpoly0 -> fp64 ring of a further stage
+// the sub-blocked form (fused_split_kernel): x2 stages with 8192- or 16384-point blocks -> vpoly0
 constexpr int kSplitVsMax = 5056; // valid samples of a sub-block: (32 + Vs + 32) 16-byte LDS elements, two workgroups per CU
 bool fused_split_supported(int log2n, int L, int ksteps);
-hipError_t launch_fused_split(const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
+// omode: 0 = float frames straight into FastIo::out (every output of the launch lies inside it, 8-byte aligned), 1 = the next
+// fifo's fp64 ring (out64), 2 = float frames wherever the output fifo has them (out / out_ring)
+hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
 
 struct PolyArgs {
   const double *tab;     // [phase][tap][order+1]

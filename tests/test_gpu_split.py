@@ -1,5 +1,5 @@
-"""GPU tests of the sub-blocked fused path (fused_fast_kernel<12, KS, true, true>): x2 stages with 8192- or 16384-point
-blocks -> vpoly0 -> a further stage, each block of the reference computed as several 4096-point component transforms
+"""GPU tests of the sub-blocked fused path (fused_split_kernel<KS, OMODE>): x2 stages with 8192- or 16384-point blocks
+-> vpoly0 (-> a further stage), each block of the reference computed as several 4096-point component transforms
 (DESIGN.md 4 "Sub-blocked fused launch").  Everything against the CPU oracle through the C ABI, at the one parity bar."""
 import os
 import subprocess
@@ -14,12 +14,12 @@ from parity import assert_parity, compare_f32
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SPLIT_KERNELS = tuple("rsmp::fused_fast_kernel<12, %d, true, true>" % ks for ks in (7, 8, 9))
+SPLIT_KERNELS = tuple("rsmp::fused_split_kernel<%d, %d>" % (ks, om) for ks in (7, 8, 9) for om in (0, 1, 2))
 
 
 def _plan_is_split_shaped(fi, fo, **kw):
     st = F.describe_plan(fi, fo, **kw)["stages"]
-    return (len(st) >= 3 and st[0]["kind"] == "dft" and st[0]["L"] == 2 and st[0]["dft_length"] in (8192, 16384)
+    return (len(st) >= 2 and st[0]["kind"] == "dft" and st[0]["L"] == 2 and st[0]["dft_length"] in (8192, 16384)
             and st[1]["kind"] == "poly" and st[1]["interp_order"] == 0)
 
 
@@ -37,6 +37,14 @@ def _kernels_of(r, x, chunk):
     (44100, 192000, 2, {"bandwidth": 97.0}),       # 8192-point blocks: sub-blocks share one window and differ by their shift
     (44100, 192000, 4, {"bandwidth": 98.0}),       # ... with a longer filter (1425 taps)
     (22050, 96000, 2, {"bandwidth": 99.0}),
+    # the polyphase stage LAST (float frames out): what a steep passband makes of the common conversions
+    (44100, 48000, 2, {"bandwidth": 99.0}),
+    (44100, 96000, 2, {"bandwidth": 98.0}),
+    (44100, 96000, 6, {"bandwidth": 99.0}),
+    (48000, 44100, 2, {"bandwidth": 99.0}),
+    (48000, 44100, 4, {"bandwidth": 97.0}),
+    (22050, 64000, 2, {"bandwidth": 99.0}),        # 640 phases (more residue pairs than the workgroup has threads: crashed RR_open once)
+    (8000, 44100, 2, {"bandwidth": 99.0}),         # 441 phases: the last 16-residue group is partial
 ])
 def test_sub_blocked_chain_matches_the_oracle(fi, fo, nch, kw):
     if not _plan_is_split_shaped(fi, fo, **kw):
@@ -109,7 +117,7 @@ def test_sub_blocked_and_unfused_paths_agree():
         "r.profile(True)\n"
         "y = r.process(x, chunk=50000)\n"
         "names = sorted({k['kernel'] for k in r.profile_report()})\n"
-        "assert not any('true, true' in n for n in names), names\n"
+        "assert not any('fused_split' in n for n in names), names\n"
         "np.save(sys.argv[1], y)\n" % (ROOT, os.path.join(ROOT, "tests")))
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "split_ref_%d.npy" % os.getpid())
     env = dict(os.environ, RSMP_NO_SPLIT="1")
@@ -124,3 +132,60 @@ def test_sub_blocked_and_unfused_paths_agree():
     assert_parity(y_old, ref)
     rep = compare_f32(y_new, y_old)
     assert rep["max_ulp"] <= 1.0 and rep["rel_rms"] <= 1e-7, rep
+
+
+@pytest.mark.parametrize("fi,fo,nch,kw", [(44100, 48000, 2, {"bandwidth": 99.0}), (44100, 96000, 4, {"bandwidth": 98.0})])
+def test_sub_blocked_float_output_in_every_place_the_fifo_can_have_it(fi, fo, nch, kw):
+    """The polyphase stage is the last one: outputs go straight into the caller's buffer (flow with room for everything:
+    OMODE 0), into the output fifo's ring (push without a destination: OMODE 2), or partly into each (a flow whose buffer is
+    smaller than what the push produces; a buffer that is only 4-byte aligned)."""
+    torch = pytest.importorskip("torch")
+    P, S = 100000, 3
+    xs = np.stack([lcg_noise(P, nch, 900 + k).reshape(P, nch) for k in range(S)])
+    refs = []
+    for k in range(S):
+        o = Oracle(fi, fo, nch, **kw)
+        o.push(xs[k])
+        refs.append(o.pull_all())
+    total = refs[0].shape[0]
+    xin = torch.from_numpy(xs).cuda()
+
+    def names_of(r):
+        return {rec["kernel"] for rec in r.profile_report()}
+
+    # (a) room for everything
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    r.profile(True)
+    cap = total + 4096
+    y = torch.empty((S, cap, nch), dtype=torch.float32, device="cuda")
+    iu, og = r.flow_device(xin, P, y, cap)
+    torch.cuda.synchronize()
+    assert (iu, og) == (P, total)
+    assert any(n.endswith(", 0>") and "fused_split" in n for n in names_of(r)), names_of(r)
+    for k in range(S):
+        assert_parity(y[k, :og].cpu().numpy(), refs[k])
+    # (b) push without a destination, pull afterwards
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    r.profile(True)
+    r.push_device(xin, P)
+    y2 = torch.empty((S, cap, nch), dtype=torch.float32, device="cuda")
+    n = r.pull_device(y2, cap)
+    torch.cuda.synchronize()
+    assert n == total
+    assert any(n_.endswith(", 2>") and "fused_split" in n_ for n_ in names_of(r)), names_of(r)
+    for k in range(S):
+        assert_parity(y2[k, :n].cpu().numpy(), refs[k])
+    # (c) a destination that takes a third of it, only 4-byte aligned; the rest is pulled later
+    r = F.Resampler(fi, fo, nch=nch, nstreams=S, **kw)
+    small = total // 3
+    raw = torch.zeros(S * small * nch + 1, dtype=torch.float32, device="cuda")
+    y3 = raw[1:].view(S, small, nch)
+    assert y3.data_ptr() % 8 == 4
+    iu, og = r.flow_device(xin, P, y3, small)
+    assert (iu, og) == (P, small)
+    rest = torch.empty((S, cap, nch), dtype=torch.float32, device="cuda")
+    n = r.pull_device(rest, cap)
+    torch.cuda.synchronize()
+    assert small + n == total
+    for k in range(S):
+        assert_parity(np.concatenate([y3[k].cpu().numpy(), rest[k, :n].cpu().numpy()]), refs[k])

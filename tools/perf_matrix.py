@@ -22,6 +22,11 @@ CASES = [
     ("44.1k->48k 2ch Normal", 44100, 48000, 2, 256, {"quality": 1}),
     ("48k->192k 2ch (dft x4)", 48000, 192000, 2, 256, {}),
     ("44.1k->176.4k 8ch (dft x4)", 44100, 176400, 8, 32, {}),
+    # steep passbands: x2 stages with 8192 / 16384-point blocks (sub-blocked fused kernel; RSMP_NO_SPLIT=1 = the unfused path)
+    ("44.1k->48k 2ch bw99", 44100, 48000, 2, 256, {"bandwidth": 99.0}),
+    ("44.1k->96k 2ch bw99", 44100, 96000, 2, 256, {"bandwidth": 99.0}),
+    ("44.1k->96k 2ch bw98", 44100, 96000, 2, 256, {"bandwidth": 98.0}),
+    ("48k->44.1k 2ch bw99", 48000, 44100, 2, 256, {"bandwidth": 99.0}),
 ]
 
 
@@ -66,7 +71,7 @@ if __name__ == "__main__":
         if out:
             out.write(line + "\n"); out.flush()
     lib = F.ratelib.lib_path()
-    trailer = {"trailer": True, "wall_s": round(time.time() - t_start, 1), "device": torch.cuda.get_device_name(0),
+    trailer = {"trailer": True, "env": {k: v for k, v in os.environ.items() if k.startswith("RSMP_")}, "wall_s": round(time.time() - t_start, 1), "device": torch.cuda.get_device_name(0),
                "lib_sha1": hashlib.sha1(open(lib, "rb").read()).hexdigest()[:12]}
     print(json.dumps(trailer), flush=True)
     if out:
