@@ -180,6 +180,43 @@ const double2 *Engine::twiddles8(int log2m)
   return d_tw8_[log2m];
 }
 
+// Can dft stage i and the rational polyphase stage behind it run as the sub-blocked fused kernel (fused_split_kernel)?  If
+// so: sub-blocks per block and valid samples per sub-block.  The kernel has no generic form behind it, so everything it
+// needs is decided here, once, from the plan: x2 stage first in the chain (float frames in), even channel count, blocks of
+// 8192 ... 32768 points whose filter leaves >= 1024 valid samples in a pair of 4096-point component transforms, matrix-pipe tiles.
+bool Engine::split_geometry(int i, int &nsub, int &vs) const
+{
+  nsub = vs = 0;
+  const Knobs &kn = knobs();
+  const int ns = int(plan_.stages.size());
+  if (i != 0 || i + 1 >= ns || kn.no_fuse || kn.no_mfma || (nch_ & 1)) return false;
+  const StageSpec &d = plan_.stages[i], &p = plan_.stages[i + 1];
+  if (d.kind != StageKind::Dft || p.kind != StageKind::Poly || p.order != 0 || d.step != 1 || d.L != 2 || d.remL0 != 0) return false;
+  const DftFilter &f = plan_.dft[d.filt];
+  const int log2n = ilog2(f.N), V = f.N - (f.num_taps - 1), Pref = f.N / 2;
+  const int pstep = int(p.step64 >> 32), at0 = int(p.at0 >> 32);
+  int d4 = 0;
+  for (int rb = 0; rb < p.L; rb += 4) {
+    const long long a0 = at0 + (long long)rb * pstep, a1 = at0 + (long long)std::min(rb + 3, p.L - 1) * pstep;
+    d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
+  }
+  const int KS = std::max(7, (p.n + d4 + 3) / 4);
+  const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
+  if ((V & 1) || p.L < 64 || p.n > 32 || max_seam > 64 || !fused_split_supported(log2n, d.L, KS)) return false;
+  // the longest sub-block the component transforms leave valid (and the LDS image holds), then an even split
+  const int vmax = std::min(kSplitVsMax, (2 * 4096 - (f.num_taps - 1)) & ~1);
+  if (vmax < 1024) return false;
+  const int n_ = (V + vmax - 1) / vmax, v_ = (((V + n_ - 1) / n_) + 1) & ~1;
+  if ((n_ - 1) * v_ >= V) return false; // (cannot happen for V >> nsub)
+  for (int k = 0; k < n_; ++k) {
+    const SubBlock sb = sub_block(k, V, v_, Pref);
+    if ((sb.len & 1) || sb.len < 2 * p.n || 2 * sb.shift + sb.len + (f.num_taps - 1) > 8192) return false;
+  }
+  nsub = n_;
+  vs = v_;
+  return true;
+}
+
 int Engine::init(const Config &cfg, int nch, int nstreams)
 {
   int rc = make_plan(cfg, plan_);
@@ -223,8 +260,10 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
       const int log2n = ilog2(Ng);
       const int log2p = fdomain_up(sp.L) ? log2n - ilog2(sp.L) : log2n;
       const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
-      const bool big = log2n > 14; // the reference's long blocks: four-step transform (dftbig.hip)
-      if (big ? !big_dft_supported(log2n, log2p, log2nd) : !dft_shape_supported(log2n, log2p, log2nd)) return kInvParam;
+      int sub_n = 0, sub_v = 0;
+      const bool sub = split_geometry(i, sub_n, sub_v); // runs as fused_split_kernel: no transform of the block's own length
+      const bool big = log2n > 14 && !sub; // the reference's long blocks: four-step transform (dftbig.hip)
+      if (!sub && (big ? !big_dft_supported(log2n, log2p, log2nd) : !dft_shape_supported(log2n, log2p, log2nd))) return kInvParam;
       st.remL = sp.remL0;
       if (!d_G_[sp.filt]) { // G = DFT_N(L * h placed at (i + N - taps + 1) mod N) / N, rate_base.h:173-175
         std::vector<cplx> g(Ng);
@@ -270,7 +309,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
         bg.ws_items = int(std::max<long long>(1, std::min<long long>((256LL << 20) / (16LL * Ng), std::max(4 * npairs, 16))));
         ALLOC_TRY(&bg.w1, size_t(bg.ws_items) * (size_t(1) << log2p) * sizeof(double2));
         ALLOC_TRY(&bg.w2, size_t(bg.ws_items) * (size_t(1) << log2nd) * sizeof(double2));
-      } else if (!twiddles(log2p) || !twiddles(log2nd)) return kNoMem;
+      } else if (!sub && (!twiddles(log2p) || !twiddles(log2nd))) return kNoMem;
       double r = double(sp.L);
       if (sp.step > 0) r /= sp.step; else r /= double(1 << -sp.step);
       rate *= r;
@@ -309,29 +348,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     // either last (float frames out) or feeding a further stage (fp64 ring out).  There is no generic kernel behind it, so
     // everything is decided here.
     int split_nsub = 0, split_vs = 0;
-    {
-      const int V = f.N - (f.num_taps - 1), Pref = f.N / 2;
-      int d4 = 0;
-      for (int rb = 0; rb < p.L; rb += 4) {
-        const long long a0 = at0 + (long long)rb * pstep, a1 = at0 + (long long)std::min(rb + 3, p.L - 1) * pstep;
-        d4 = std::max(d4, int(a1 / p.L - a0 / p.L));
-      }
-      const int KS = std::max(7, (p.n + d4 + 3) / 4);
-      if (i == 0 && d.L == 2 && d.remL0 == 0 && !(nch_ & 1) && !(V & 1) && p.L >= 64 && p.n <= 32 && max_seam <= 64 &&
-          !kn.no_fuse && !kn.no_mfma && fused_split_supported(log2n, d.L, KS)) {
-        // the longest sub-block the component transforms leave valid (and the LDS image holds), then an even split
-        const int vmax = std::min(kSplitVsMax, (2 * 4096 - (f.num_taps - 1)) & ~1);
-        if (vmax >= 1024) {
-          split_nsub = (V + vmax - 1) / vmax;
-          split_vs = (((V + split_nsub - 1) / split_nsub) + 1) & ~1;
-          if ((split_nsub - 1) * split_vs >= V) split_nsub = 0; // (cannot happen for V >> nsub)
-          for (int k = 0; k < split_nsub; ++k) {
-            const SubBlock sb = sub_block(k, V, split_vs, Pref);
-            if ((sb.len & 1) || sb.len < 2 * p.n || 2 * sb.shift + sb.len + (f.num_taps - 1) > 8192) split_nsub = 0;
-          }
-        }
-      }
-    }
+    split_geometry(i, split_nsub, split_vs);
     const bool split = split_nsub > 0;
     const int threads = split ? 256 : f.N / 16;
     if (!split && (NG > threads || !fused_shape_supported(log2n, log2p, p.n, p.n + dmax, max_seam))) continue;
@@ -364,6 +381,7 @@ int Engine::init(const Config &cfg, int nch, int nstreams)
     // reads its slots while fused(k+1) fills the next ones)
     fu.blk_cap = 64;
     while (fu.blk_cap < kFusedMaxBlocks && double(C_ + 1) * double(4 * fu.blk_cap) * 512 <= kn.seam_ring_mb * 1048576.0) fu.blk_cap *= 2;
+    while (fu.blk_cap < 8 * split_nsub) fu.blk_cap *= 2; // (sub-blocked: the table counts sub-blocks; at least 6 whole blocks per launch)
     fu.slots = 2 * fu.blk_cap;
     ALLOC_TRY(&fu.blk_dev, size_t(2 * fu.blk_cap) * sizeof(FusedBlock)); // two halves: launch k uses half k & 1 (see advance)
     const size_t bytes = size_t(C_ + 1) * fu.slots * 2 * 32 * sizeof(double);
@@ -923,12 +941,13 @@ int Engine::advance_dft(Pass &ps, int i)
     const int log2p = fdomain_up(L) ? log2n - ilog2(L) : log2n;
     const int log2nd = sp.step < 0 ? log2n + sp.step : log2n;
     const bool big = big_[i].on;
-    a.tw_fwd = twiddles(big ? log2p - 4 : log2p);
-    a.tw_inv = twiddles(big ? log2nd - 4 : log2nd);
-    a.tw_fwd8 = (!big && log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
-    if (!big && log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
-    a.tw_inv8 = (!big && log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
-    if (!big && log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
+    const bool sub = fused && fuse_[i].nsub > 0; // sub-blocked fused launch: 4096-point tables, set where it is launched
+    a.tw_fwd = sub ? nullptr : twiddles(big ? log2p - 4 : log2p);
+    a.tw_inv = sub ? nullptr : twiddles(big ? log2nd - 4 : log2nd);
+    a.tw_fwd8 = (!sub && !big && log2p >= 6 && log2p <= 13) ? twiddles8(log2p) : nullptr;
+    if (!sub && !big && log2p >= 6 && log2p <= 13 && !a.tw_fwd8) return kNoMem;
+    a.tw_inv8 = (!sub && !big && log2nd >= 6 && log2nd <= 12) ? twiddles8(log2nd) : nullptr;
+    if (!sub && !big && log2nd >= 6 && log2nd <= 12 && !a.tw_inv8) return kNoMem;
     a.B0 = B0;
     a.out_offset = out_offset;
     a.nblocks = nblocks;

@@ -123,6 +123,7 @@ private:
   int advance_poly(Pass &ps, int i);
   int advance_half(Pass &ps, int i);
   int launch_fused_pair(Pass &ps, int i, long long count, long long step);
+  bool split_geometry(int i, int &nsub, int &vs) const;
   int launch_polymf_stage(Pass &ps, int i, long long count, long long step);
   int launch_poly_stage(Pass &ps, int i, long long count, long long step);
   int ensure_ring(int f, long long live_needed);

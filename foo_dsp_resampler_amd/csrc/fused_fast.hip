@@ -605,7 +605,7 @@ template <int KS, int OMODE> static hipError_t launch_split_t(const FusedArgs &a
 
 bool fused_split_supported(int log2n, int L, int ksteps)
 {
-  return !knobs().no_fast && !knobs().no_split && L == 2 && (log2n == 13 || log2n == 14) && ksteps >= 7 && ksteps <= 9;
+  return !knobs().no_fast && !knobs().no_split && L == 2 && log2n >= 13 && log2n <= 15 && ksteps >= 7 && ksteps <= 9;
 }
 
 hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
@@ -613,7 +613,7 @@ hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, h
   // what the kernel's indexing assumes, checked where the launch is made
   if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || a.d.Vs > kSplitVsMax || (a.d.V & 1) || a.d.nblocks % a.d.nsub || omode < 0 || omode > 2 ||
       (omode == 1 ? !io.out64 : omode == 2 ? !io.out_ring : !io.out) ||
-      (a.d.Pref != 4096 && a.d.Pref != 8192) || a.d.nsub * a.d.Vs < a.d.V || (a.d.nsub - 1) * a.d.Vs >= a.d.V || (io.nch & 1))
+      (a.d.Pref != 4096 && a.d.Pref != 8192 && a.d.Pref != 16384) || a.d.nsub * a.d.Vs < a.d.V || (a.d.nsub - 1) * a.d.Vs >= a.d.V || (io.nch & 1))
     return hipErrorInvalidValue;
   for (int i = 0; i < a.d.nsub; ++i) { // every sub-block's samples must be free of the component transforms' wrap-around
     const SubBlock sb = sub_block(i, a.d.V, a.d.Vs, a.d.Pref);

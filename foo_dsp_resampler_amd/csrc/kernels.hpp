@@ -139,7 +139,11 @@ struct FusedBlock {
 #ifndef RSMP_WG4
 #define RSMP_WG4 0
 #endif
-constexpr int kFusedSA = RSMP_WG4 ? 9 : 12, kFusedSB0 = kFusedSA - 2, kFusedWaves = RSMP_WG4 ? 4 : 3;
+// RSMP_WG2 (experiment): two workgroups per CU with 256 VGPRs each, the whole block (V <= 3584) in the first image
+#ifndef RSMP_WG2
+#define RSMP_WG2 0
+#endif
+constexpr int kFusedSA = RSMP_WG2 ? 14 : RSMP_WG4 ? 9 : 12, kFusedSB0 = kFusedSA - 2, kFusedWaves = RSMP_WG2 ? 2 : RSMP_WG4 ? 4 : 3;
 
 // Closed forms of a block's bookkeeping; evaluated by fused_prep_kernel on the device (one thread per block of the
 // launch) and by the engine for its consistency checks.

@@ -39,7 +39,10 @@ int RRX_device(const RR_handle *h);
 /* Device-pointer forms of RR_push / RR_pull / RR_flow (rate/ratelib.h:75-77).  Pointers are HBM
  * addresses valid on the handle's HIP stream; calls only enqueue work (no host synchronisation),
  * the frame counts they return are exact because availability never depends on sample values.
- * RRX_flow_device consumes the input in place and writes new output straight into d_obuf. */
+ * RRX_flow_device consumes the input in place and writes new output straight into d_obuf.
+ * Ordering is the caller's: whatever filled d_ibuf (or last wrote d_obuf, e.g. a zero fill) on ANOTHER stream must have
+ * completed, or be ordered before the handle's stream by an event, when the call is made; work on the handle's own
+ * stream (RRX_set_stream) is ordered by the stream itself. */
 int RRX_push_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, size_t isamp);
 int RRX_pull_device(RR_handle *h, fb_sample_t *d_obuf, size_t out_stride, size_t osamp, size_t *ogen);
 int RRX_flow_device(RR_handle *h, const fb_sample_t *d_ibuf, size_t in_stride, fb_sample_t *d_obuf, size_t out_stride,

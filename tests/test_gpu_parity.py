@@ -7,6 +7,7 @@ import pytest
 
 import foo_dsp_resampler_amd as F
 from oracle_binding import Oracle, lcg_noise
+from devbuf import dev_zeros
 from parity import assert_parity, compare_f32
 
 pytestmark = pytest.mark.gpu
@@ -188,11 +189,11 @@ def test_device_pointer_api_and_full_size_properties():
     r = F.Resampler(44100, 96000, nch=nch, nstreams=S)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * 96000 / 44100) + 4096
-    y = torch.zeros((S, cap, nch), device="cuda")
+    y = dev_zeros((S, cap, nch))
     iu, og = r.flow_device(x, n, y, cap)
     assert iu == n
     r.drain()
-    tail = torch.zeros((S, cap, nch), device="cuda")
+    tail = dev_zeros((S, cap, nch))
     og2 = r.pull_device(tail, cap)
     r.sync()
     total = og + og2
@@ -219,11 +220,11 @@ def test_bench_workload_against_oracle():
     r = F.Resampler(fi, fo, nch=nch, nstreams=S)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * fo / fi) + 4096
-    y = torch.zeros((S, cap, nch), device="cuda")
+    y = dev_zeros((S, cap, nch))
     iu, og = r.flow_device(x, n, y, cap)
     assert iu == n
     r.drain()
-    tail = torch.zeros((S, 8192, nch), device="cuda")
+    tail = dev_zeros((S, 8192, nch))
     og2 = r.pull_device(tail, 8192)
     r.sync()
     assert og + og2 == int(n * fo / fi + .5)

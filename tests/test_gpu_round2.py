@@ -11,6 +11,7 @@ import pytest
 import foo_dsp_resampler_amd as F
 import foo_dsp_resampler_amd.ratelib as R
 from oracle_binding import Oracle, lcg_noise
+from devbuf import dev_zeros
 from parity import assert_parity, compare_f32
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +31,7 @@ def test_cfg4_per_gpu_shard_against_oracle():
     r = F.Resampler(fi, fo, nch=nch, nstreams=S)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * fo / fi) + 4096
-    y = torch.zeros((S, cap, nch), device="cuda")
+    y = dev_zeros((S, cap, nch))
     got = 0
     for lo, hi in ((0, 41000), (41000, n)):
         seg = x[:, lo:hi].contiguous()
@@ -103,7 +104,7 @@ def test_set_stream_does_not_take_ownership():
     ref = F.Resampler(fi, fo, nch).process(x.cpu().numpy())
     side = torch.cuda.Stream()
     r = F.Resampler(fi, fo, nch)
-    y = torch.zeros((cap, nch), device="cuda")
+    y = dev_zeros((cap, nch))
     torch.cuda.synchronize()
     r.set_stream(side.cuda_stream)
     iu, og = r.flow_device(x[:30000].contiguous(), 30000, y, cap)

@@ -14,6 +14,7 @@ import pytest
 import foo_dsp_resampler_amd as F
 from foo_dsp_resampler_amd import ratelib as R
 from oracle_binding import Oracle, lcg_noise
+from devbuf import dev_zeros
 from parity import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -122,13 +123,13 @@ def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
     cap = int(n * fo / fi) + 65536  # a push's output varies by a block or two of the last stage around the mean
     ys, ogs = [], []
     for _ in range(2):
-        y = torch.zeros((S, cap, nch), device="cuda")
+        y = dev_zeros((S, cap, nch))
         iu, og = r.flow_device(x, n, y, cap)
         assert iu == n
         ys.append(y)
         ogs.append(og)
     r.drain()
-    tail = torch.zeros((S, 16384, nch), device="cuda")
+    tail = dev_zeros((S, 16384, nch))
     og2 = r.pull_device(tail, 16384)
     r.sync()
     assert sum(ogs) + og2 == int(2 * n * fo / fi + .5)
@@ -244,7 +245,7 @@ def test_host_mirror_against_oracle_call_by_call(fi, fo, nch, S):
         if mode == 0:
             continue  # leave everything where it is: the next push finds frames in the mirror
         if mode == 3 and S == 1:  # device pull of part of what is there
-            t = torch.zeros((max(want, 1), nch), device="cuda")
+            t = dev_zeros((max(want, 1), nch))
             got_n = r.pull_device(t, want) if want else 0
             r.sync()
             ref = os_[0].pull(want) if want else np.empty((0, nch), np.float32)
@@ -296,12 +297,12 @@ def test_many_launches_per_push():
         "cap = int(n * fo / fi) + 65536\n"
         "ys, ogs = [], []\n"
         "for _ in range(2):\n"
-        "    y = torch.zeros((S, cap, nch), device='cuda'); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
+        "    y = torch.zeros((S, cap, nch), device='cuda'); torch.cuda.synchronize(); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
         "launches = max(k['launches'] for k in r.profile_report() if 'fused' in k['kernel'] and 'prep' not in k['kernel'])\n"
         "r.profile(False)\n"
         "for _ in range(2):\n"
-        "    y = torch.zeros((S, cap, nch), device='cuda'); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
-        "r.drain(); tail = torch.zeros((S, 16384, nch), device='cuda'); og2 = r.pull_device(tail, 16384); r.sync()\n"
+        "    y = torch.zeros((S, cap, nch), device='cuda'); torch.cuda.synchronize(); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
+        "r.drain(); tail = torch.zeros((S, 16384, nch), device='cuda'); torch.cuda.synchronize(); og2 = r.pull_device(tail, 16384); r.sync()\n"
         "for s in (0, 31, 63):\n"
         "    o = Oracle(fi, fo, nch); xs = x[s].cpu().numpy()\n"
         "    for k in range(4):\n"

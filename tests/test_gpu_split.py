@@ -19,7 +19,7 @@ SPLIT_KERNELS = tuple("rsmp::fused_split_kernel<%d, %d>" % (ks, om) for ks in (7
 
 def _plan_is_split_shaped(fi, fo, **kw):
     st = F.describe_plan(fi, fo, **kw)["stages"]
-    return (len(st) >= 2 and st[0]["kind"] == "dft" and st[0]["L"] == 2 and st[0]["dft_length"] in (8192, 16384)
+    return (len(st) >= 2 and st[0]["kind"] == "dft" and st[0]["L"] == 2 and st[0]["dft_length"] in (8192, 16384, 32768)
             and st[1]["kind"] == "poly" and st[1]["interp_order"] == 0)
 
 
@@ -45,6 +45,8 @@ def _kernels_of(r, x, chunk):
     (48000, 44100, 4, {"bandwidth": 97.0}),
     (22050, 64000, 2, {"bandwidth": 99.0}),        # 640 phases (more residue pairs than the workgroup has threads: crashed RR_open once)
     (8000, 44100, 2, {"bandwidth": 99.0}),         # 441 phases: the last 16-residue group is partial
+    (44100, 96000, 2, {"bandwidth": 99.5}),        # 32768-point blocks (5493 taps): eleven sub-blocks of 2480 samples
+    (44100, 192000, 4, {"bandwidth": 99.5}),
 ])
 def test_sub_blocked_chain_matches_the_oracle(fi, fo, nch, kw):
     if not _plan_is_split_shaped(fi, fo, **kw):
@@ -91,6 +93,7 @@ def test_sub_blocked_batch_of_streams_and_unaligned_input():
     xin = raw[1:].view(S, P, nch)  # base address = allocation + 4 bytes
     assert xin.data_ptr() % 8 == 4
     xin.copy_(torch.from_numpy(xs))
+    torch.cuda.synchronize()  # torch's stream filled the input; the handle works on its own stream
     cap = int(P * fo / fi) + 65536
     y = torch.empty((S, cap, nch), dtype=torch.float32, device="cuda")
     iu, og = r.flow_device(xin, P, y, cap)
@@ -149,6 +152,7 @@ def test_sub_blocked_float_output_in_every_place_the_fifo_can_have_it(fi, fo, nc
         refs.append(o.pull_all())
     total = refs[0].shape[0]
     xin = torch.from_numpy(xs).cuda()
+    torch.cuda.synchronize()
 
     def names_of(r):
         return {rec["kernel"] for rec in r.profile_report()}
@@ -181,6 +185,7 @@ def test_sub_blocked_float_output_in_every_place_the_fifo_can_have_it(fi, fo, nc
     raw = torch.zeros(S * small * nch + 1, dtype=torch.float32, device="cuda")
     y3 = raw[1:].view(S, small, nch)
     assert y3.data_ptr() % 8 == 4
+    torch.cuda.synchronize()  # (the zero fill of `raw` runs on torch's stream)
     iu, og = r.flow_device(xin, P, y3, small)
     assert (iu, og) == (P, small)
     rest = torch.empty((S, cap, nch), dtype=torch.float32, device="cuda")

@@ -27,6 +27,8 @@ CASES = [
     ("44.1k->96k 2ch bw99", 44100, 96000, 2, 256, {"bandwidth": 99.0}),
     ("44.1k->96k 2ch bw98", 44100, 96000, 2, 256, {"bandwidth": 98.0}),
     ("48k->44.1k 2ch bw99", 48000, 44100, 2, 256, {"bandwidth": 99.0}),
+    ("44.1k->96k 2ch bw99.5 (32768-point blocks)", 44100, 96000, 2, 128, {"bandwidth": 99.5}),
+    ("96k->44.1k 2ch bw98 (x1, 8192-point blocks)", 96000, 44100, 2, 128, {"bandwidth": 98.0}),
 ]
 
 
