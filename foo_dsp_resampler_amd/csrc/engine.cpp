@@ -45,6 +45,7 @@ const Knobs &knobs()
     r.no_polymf = on("RSMP_NO_POLYMF");
     r.no_fast = on("RSMP_NO_FAST");
     r.no_split = on("RSMP_NO_SPLIT");
+    r.no_split2 = on("RSMP_NO_SPLIT2");
     r.no_dftx = on("RSMP_NO_DFTX");
     r.no_polyi = on("RSMP_NO_POLYI");
     r.no_polycoop = on("RSMP_NO_POLYCOOP");
@@ -203,6 +204,15 @@ bool Engine::split_geometry(int i, int &nsub, int &vs) const
   const int KS = std::max(7, (p.n + d4 + 3) / 4);
   const int max_seam = int(((long long)(p.n - 1) * p.L + pstep - 1) / pstep) + 1;
   if ((V & 1) || p.L < 64 || p.n > 32 || max_seam > 64 || !fused_split_supported(log2n, d.L, KS)) return false;
+  if (Pref == 4096) { // 8192-point blocks: the whole block from ONE pair of component transforms, polyphase stage in two rounds
+    int qb_min = at0 / p.L, qb_max = qb_min;
+    for (int rb = 0; rb < p.L; rb += 4) qb_max = std::max(qb_max, int((at0 + (long long)rb * pstep) / p.L));
+    if (fused_split_two_supported(V, f.num_taps, KS, qb_max - qb_min) && V >= 2 * p.n) {
+      nsub = 1;
+      vs = V;
+      return true;
+    }
+  }
   // the longest sub-block the component transforms leave valid (and the LDS image holds), then an even split
   const int vmax = std::min(kSplitVsMax, (2 * 4096 - (f.num_taps - 1)) & ~1);
   if (vmax < 1024) return false;
@@ -963,7 +973,7 @@ int Engine::advance_dft(Pass &ps, int i)
     a.in_limit = 0x7fffffffffffffffLL;
     a.clip_lo = -0x7fffffffffffffffLL;
     a.clip_hi = 0x7fffffffffffffffLL;
-    a.nsub = a.Vs = a.Pref = 0;
+    a.nsub = a.Vs = a.Pref = a.two = 0;
     a.Bref0 = 0;
     if (big) {
       const BigDft &bg = big_[i];
@@ -1093,7 +1103,10 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
     pa.nblocks = ntab;
     pa.nsub = fu.nsub;
     pa.Vs = fu.Vs;
-    pa.two_round = fu.cfm != nullptr && !split;
+    const bool split_two = split && fu.nsub == 1 && fu.Vs > kSplitVsMax; // whole 8192-point blocks, two rounds (split_geometry)
+    pa.two_round = fu.cfm != nullptr && (!split || split_two);
+    pa.ra_end = split_two ? kSplitRaEnd : 0;
+    pa.rb_start = split_two ? kSplitRbStart : 0;
     pa.KS = fu.KS;
     pa.qb_max = fu.qb_max;
     pa.qb_min = fu.qb_min;
@@ -1165,6 +1178,7 @@ int Engine::launch_fused_pair(Pass &ps, int i, long long count, long long step)
       if (!fr.d.tw_fwd) return kNoMem;
       fr.d.nsub = fu.nsub;
       fr.d.Vs = fu.Vs;
+      fr.d.two = split_two ? 1 : 0;
       fr.d.Pref = 1 << pend_log2p;
       fr.d.Bref0 = pend.B0;
       fr.d.B0 = pend.B0 * fu.nsub;
@@ -1280,6 +1294,7 @@ int Engine::launch_polymf_stage(Pass &ps, int i, long long count, long long step
     pa.n = 1;
     pa.nblocks = int(std::min<long long>(pm.blk_cap, t_end - t0));
     pa.two_round = 0;
+    pa.ra_end = pa.rb_start = 0;
     pa.nsub = pa.Vs = 0;
     pa.KS = pm.KS;
     pa.qb_max = 0;

@@ -91,9 +91,12 @@ constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 // seam ring, the block table and seam_kernel work on sub-blocks exactly as they do on blocks.
 // OGEN (sub-blocked form only): float frames out, each output wherever the output fifo has it -- the caller's buffer or the
 // fifo's ring (RR_push without a destination, outputs beyond the caller's capacity): fifo_put for a channel pair.
-template <int LOG2P, int KS, bool OUT64, bool SPLIT, bool OGEN>
+// TWO (sub-blocked form, 8192-point blocks): the block is ONE workgroup -- its V samples fit a pair of 4096-point component
+// transforms whole -- and the polyphase stage runs in two rounds, the second from the register slots kept across the first.
+template <int LOG2P, int KS, bool OUT64, bool SPLIT, bool OGEN, bool TWO = false>
 __device__ __forceinline__ void fused_fast_body(const FusedArgs &a, const FastIo &io)
 {
+  static_assert(!TWO || SPLIT, "two rounds from registers: sub-blocked form only");
   static_assert(!SPLIT || LOG2P == 12, "sub-blocked form: 4096-point components");
   static_assert(!OGEN || (SPLIT && !OUT64), "generic float output exists for the sub-blocked form only");
   constexpr int LOG2N = 12, N = 1 << LOG2N, P = 1 << LOG2P;
@@ -286,7 +289,23 @@ __device__ __forceinline__ void fused_fast_body(const FusedArgs &a, const FastIo
     // (store_tail), where it is 23 consecutive elements -- out of registers it took per-lane range tests and a pair of
     // conditional global stores in every one of the 16 unrolled slots (V is a run-time value): ~300 scalar and ~150 vector
     // instructions per wave for 46 doubles.
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && TWO) {
+      __syncthreads(); // the image overlays the exchange area of the last transform
+      // first image: samples [0, kSplitRaEnd) + 32 = slots 0 .. kSplitSA - 1 of both components and 16 elements of slot kSplitSA
+#pragma unroll
+      for (int s = 0; s <= kSplitSA; ++s) {
+        const int n = 2 * (tid + s * T);
+        if (n < V && (s < kSplitSA || tid < kPad / 2)) {
+          smp[n] = make_double2(z0[s].x, z0[s].y);
+          smp[n + 1] = make_double2(v[s].x, v[s].y);
+        }
+      }
+      if (tid < kPad) {
+        smp[tid - kPad] = make_double2(0.0, 0.0);
+        if (V < kSplitRaEnd + kPad) smp[V + tid] = make_double2(0.0, 0.0);
+      }
+      (void)seamA; (void)seamB;
+    } else if constexpr (SPLIT) {
       __syncthreads(); // the image overlays the exchange area of the last transform
       // element m of component r is sample 2 (m - shift) + r of the sub-block; the whole sub-block fits the image
 #pragma unroll
@@ -340,7 +359,8 @@ __device__ __forceinline__ void fused_fast_body(const FusedArgs &a, const FastIo
       a.seam[((long long)(slot * (a.d.C + 1) + cb) * 2 + 1) * 32 + tid] = t.y;
     }
   };
-  const bool tail_in_b = !SPLIT && tail0 >= kSB0 * T; // uniform: else the whole tail lies inside the first image (V <= kSB0 * T + n - 1)
+  // uniform: else the whole tail lies inside the first image (V <= kSB0 * T + n - 1)
+  const bool tail_in_b = TWO ? tail0 >= kSplitRbStart : (!SPLIT && tail0 >= kSB0 * T);
   if (!tail_in_b) store_tail(smp, 0);
   RSMP_STAMP(4)
 
@@ -534,7 +554,26 @@ __device__ __forceinline__ void fused_fast_body(const FusedArgs &a, const FastIo
   if (RSMP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
   if (RSMP_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   // round A: periods whose windows end inside the samples written above
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT && TWO) {
+    if (run) poly_round(0, fb.KA, smp, -kPad, min(V, kSplitRaEnd) + kPad - 4 * KS);
+    __syncthreads();
+    { // second image: samples [kSplitRbStart, V) from the slots kept in registers, element 0 = sample kSplitRbStart
+      double2 *l2 = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+      for (int s = kSplitSB0; s < 16; ++s) {
+        const int n = 2 * (tid + s * T);
+        if (n < V) {
+          l2[n - kSplitRbStart] = make_double2(z0[s].x, z0[s].y);
+          l2[n + 1 - kSplitRbStart] = make_double2(v[s].x, v[s].y);
+        }
+      }
+      if (tid < kPad && V > kSplitRbStart) l2[V - kSplitRbStart + tid] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    if (tail_in_b) store_tail(reinterpret_cast<const double2 *>(lds), kSplitRbStart);
+    if (run && fb.KA < fb.K) poly_round(fb.KA, fb.K, reinterpret_cast<const double2 *>(lds) - kSplitRbStart, kSplitRbStart, V + kPad - 4 * KS);
+    return;
+  } else if constexpr (SPLIT) {
     if (run) poly_round(0, fb.K, smp, -kPad, V + kPad - 4 * KS); // one round over the whole image
     return;
   }
@@ -573,6 +612,12 @@ __global__ __launch_bounds__(256, 2) void fused_split_kernel(FusedArgs a, FastIo
 {
   fused_fast_body<12, KS, OMODE == 1, true, OMODE == 2>(a, io);
 }
+// whole 8192-point blocks, polyphase stage in two rounds from registers (TWO)
+template <int KS, int OMODE>
+__global__ __launch_bounds__(256, 2) void fused_split2_kernel(FusedArgs a, FastIo io)
+{
+  fused_fast_body<12, KS, OMODE == 1, true, OMODE == 2, true>(a, io);
+}
 
 template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
@@ -589,18 +634,29 @@ template <int LOG2P, int KS, bool OUT64> static hipError_t launch_fast_t(const F
   return hipGetLastError();
 }
 
-template <int KS, int OMODE> static hipError_t launch_split_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
+template <int KS, int OMODE, bool TWO> static hipError_t launch_split_t(const FusedArgs &a, const FastIo &io, hipStream_t st)
 {
-  // the image of the longest sub-block, or the exchange area of the transforms, whichever is larger: <= 80 KB, two per CU
-  const size_t lds_max = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + kSplitVsMax + kPad) * 16);
-  const size_t lds_bytes = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + a.d.Vs + kPad) * 16);
+  // the image of the longest sub-block (TWO: the first image, the longer of the two), or the exchange area of the
+  // transforms, whichever is larger: <= 80 KB, two per CU
+  const size_t lds_max = std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + (TWO ? kSplitRaEnd : kSplitVsMax) + kPad) * 16);
+  const size_t lds_bytes = TWO ? lds_max : std::max(size_t(8) * fft_lds_doubles_halves(12), size_t(kPad + a.d.Vs + kPad) * 16);
   static DynLdsOnce attr;
-  if (hipError_t e = attr.set(reinterpret_cast<const void *>(&fused_split_kernel<KS, OMODE>), int(lds_max)); e != hipSuccess) return e;
+  const void *fn = TWO ? reinterpret_cast<const void *>(&fused_split2_kernel<KS, OMODE>) : reinterpret_cast<const void *>(&fused_split_kernel<KS, OMODE>);
+  if (hipError_t e = attr.set(fn, int(lds_max)); e != hipSuccess) return e;
   FusedArgs b = a;
   b.d.hp = io.nch >= 4 ? io.nch / 2 : 0;
   dim3 grid(item_grid(a.d.nblocks, a.d.C / 2, b.d.hp)), block(256);
-  hipLaunchKernelGGL((fused_split_kernel<KS, OMODE>), grid, block, lds_bytes, st, b, io);
+  if (TWO) hipLaunchKernelGGL((fused_split2_kernel<KS, OMODE>), grid, block, lds_bytes, st, b, io);
+  else hipLaunchKernelGGL((fused_split_kernel<KS, OMODE>), grid, block, lds_bytes, st, b, io);
   return hipGetLastError();
+}
+
+// V samples of an 8192-point block in two LDS images: the second must reach the block's end, and every 4-residue block's
+// windows (spread qb_spread samples) must fit the overlap of the two
+bool fused_split_two_supported(int V, int taps, int ksteps, int qb_spread)
+{
+  return !knobs().no_split2 && !(V & 1) && V == 8192 - (taps - 1) && V > kSplitVsMax && V - kSplitRbStart + kPad <= kSplitRaEnd + kPad &&
+         qb_spread + 4 * ksteps + 4 <= kSplitRaEnd - kSplitRbStart + kPad && ksteps >= 7 && ksteps <= 9;
 }
 
 bool fused_split_supported(int log2n, int L, int ksteps)
@@ -611,7 +667,10 @@ bool fused_split_supported(int log2n, int L, int ksteps)
 hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname)
 {
   // what the kernel's indexing assumes, checked where the launch is made
-  if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || a.d.Vs > kSplitVsMax || (a.d.V & 1) || a.d.nblocks % a.d.nsub || omode < 0 || omode > 2 ||
+  if (a.d.two) { // whole 8192-point blocks: one "sub-block" per block, two rounds
+    if (a.d.nsub != 1 || a.d.Vs != a.d.V || a.d.Pref != 4096 || a.d.V <= kSplitVsMax || a.d.V > 8192 || (a.d.V & 1)) return hipErrorInvalidValue;
+  } else if (a.d.Vs > kSplitVsMax) return hipErrorInvalidValue;
+  if (a.d.nsub < 1 || a.d.Vs < 64 || (a.d.Vs & 1) || (a.d.V & 1) || a.d.nblocks % a.d.nsub || omode < 0 || omode > 2 ||
       (omode == 1 ? !io.out64 : omode == 2 ? !io.out_ring : !io.out) ||
       (a.d.Pref != 4096 && a.d.Pref != 8192 && a.d.Pref != 16384) || a.d.nsub * a.d.Vs < a.d.V || (a.d.nsub - 1) * a.d.Vs >= a.d.V || (io.nch & 1))
     return hipErrorInvalidValue;
@@ -621,9 +680,13 @@ hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, h
     if (sb.win < 0 || sb.shift < 0 || sb.shift + sb.len / 2 + (ov + 1) / 2 > 4096 || (sb.len & 1) || sb.win + 4096 > a.d.Pref) return hipErrorInvalidValue;
   }
 #define RSMP_SPLIT_CASE(ks, om)                                                        \
-  if (a.KS == ks && omode == om) {                                                     \
+  if (a.KS == ks && omode == om && !a.d.two) {                                         \
     if (kname) *kname = "rsmp::fused_split_kernel<" #ks ", " #om ">";                  \
-    return launch_split_t<ks, om>(a, io, st);                                          \
+    return launch_split_t<ks, om, false>(a, io, st);                                   \
+  }                                                                                    \
+  if (a.KS == ks && omode == om && a.d.two) {                                          \
+    if (kname) *kname = "rsmp::fused_split2_kernel<" #ks ", " #om ">";                 \
+    return launch_split_t<ks, om, true>(a, io, st);                                    \
   }
   // (9 k-steps: 80 phases at step 147, the windows of a 4-residue block spread over 34 samples)
   RSMP_SPLIT_CASE(7, 0) RSMP_SPLIT_CASE(7, 1) RSMP_SPLIT_CASE(7, 2) RSMP_SPLIT_CASE(8, 0) RSMP_SPLIT_CASE(8, 1) RSMP_SPLIT_CASE(8, 2)

@@ -78,6 +78,7 @@ struct DftArgs {
   // `nsub` sub-blocks of `Vs` valid samples (the last one shorter) on 4096-point component transforms; B0 / nblocks then
   // count SUB-blocks (B0 = Bref0 * nsub) and G holds the two component spectra.  nsub = 0: not sub-blocked.
   int nsub, Vs;
+  int two;               // 1: whole 8192-point blocks (nsub = 1, Vs = V), polyphase stage in two rounds (kSplitRaEnd / kSplitRbStart)
   int Pref;              // inputs a reference block spans (N / L)
   long long Bref0;       // first reference block of the launch
 };
@@ -151,6 +152,8 @@ struct FusedPrepArgs {
   long long b_offset, B0, at0; // as in FusedArgs / DftArgs
   int V, polyL, step, n, nblocks;
   int two_round, KS, qb_max;   // matrix-pipe variant: split of the periods over its two LDS images
+  int ra_end, rb_start;        // ... the first image holds samples [0, ra_end) (+ 32), the second starts at rb_start; 0 = the lean
+                               // kernel's kFusedSA * 256 / kFusedSB0 * 256
   int qb_min;                  // (smallest / largest window start of a 4-residue block, relative to its period)
   long long clip_lo, clip_hi;  // only outputs with index in [clip_lo, clip_hi) belong to this launch (standalone stage)
   int nsub, Vs;                // sub-blocked launch (DftArgs::nsub): entry k is sub-block k % nsub of reference block B0 + k / nsub
@@ -184,14 +187,15 @@ __host__ __device__ inline FusedBlock fused_block_info(const FusedPrepArgs &p, i
     fb.seam_q0 = int(q0 - (b0 - (p.n - 1)));
     fb.seam_ph0 = int(a0 - q0 * p.polyL);
   }
-  if (p.two_round && V > kFusedSA * 256) { // periods whose (padded) windows end inside the first LDS image
-    const int a_hi = kFusedSA * 256 + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
+  const int ra_end = p.ra_end > 0 ? p.ra_end : kFusedSA * 256, rb_start = p.ra_end > 0 ? p.rb_start : kFusedSB0 * 256;
+  if (p.two_round && V > ra_end) { // periods whose (padded) windows end inside the first LDS image
+    const int a_hi = ra_end + 32 - 4 * p.KS - 3, num = a_hi - fb.base_li - p.qb_max;
     const int ka = num < 0 ? 0 : num / p.step + 1;
     fb.KA = ka < fb.K ? ka : fb.K;
     // a multiple of 4 periods in the first image when the second one can take the rest: the two rounds then need
     // ceil(K / 4) column steps of 4 periods together instead of one more
     const int k4 = fb.KA & ~3;
-    if (fb.KA < fb.K && k4 > 0 && fb.base_li + p.qb_min + k4 * p.step >= kFusedSB0 * 256) fb.KA = k4;
+    if (fb.KA < fb.K && k4 > 0 && fb.base_li + p.qb_min + k4 * p.step >= rb_start) fb.KA = k4;
   }
   return fb;
 }
@@ -242,10 +246,15 @@ bool fused_fast_supported(int log2n, int log2p, int ksteps);
 hipError_t launch_fused_fast(int log2p, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
 // the sub-blocked form (fused_split_kernel): x2 stages with 8192- or 16384-point blocks -> vpoly0
 constexpr int kSplitVsMax = 5056; // valid samples of a sub-block: (32 + Vs + 32) 16-byte LDS elements, two workgroups per CU
+// 8192-point blocks fit ONE pair of component transforms whole (V = 8192 - (taps - 1) samples): one workgroup, the polyphase
+// stage in two rounds -- samples [0, kSplitRaEnd) (register slots 0 .. 8 of both components) first, [kSplitRbStart, V) from
+// the slots kept in registers (8 .. 15) afterwards
+constexpr int kSplitSA = 9, kSplitSB0 = 8, kSplitRaEnd = 2 * kSplitSA * 256, kSplitRbStart = 2 * kSplitSB0 * 256;
 bool fused_split_supported(int log2n, int L, int ksteps);
 // omode: 0 = float frames straight into FastIo::out (every output of the launch lies inside it, 8-byte aligned), 1 = the next
 // fifo's fp64 ring (out64), 2 = float frames wherever the output fifo has them (out / out_ring)
 hipError_t launch_fused_split(int omode, const FusedArgs &a, const FastIo &io, hipStream_t st, const char **kname = nullptr);
+bool fused_split_two_supported(int V, int taps, int ksteps, int qb_spread); // the whole-block two-round form (8192-point blocks)
 
 struct PolyArgs {
   const double *tab;     // [phase][tap][order+1]

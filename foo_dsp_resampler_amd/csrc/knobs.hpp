@@ -72,7 +72,7 @@
 namespace rsmp {
 
 struct Knobs {
-  bool no_fuse = false, no_mfma = false, no_polymf = false, no_fast = false, no_split = false, no_dftx = false, no_polyi = false,
+  bool no_fuse = false, no_mfma = false, no_polymf = false, no_fast = false, no_split = false, no_split2 = false, no_dftx = false, no_polyi = false,
        no_polycoop = false, spread_vector = false, no_side = false, no_graph = false, stamps = false, occ = false,
        test_hooks = false;
   double slab_mb = 1536.0, seam_ring_mb = 1280.0;

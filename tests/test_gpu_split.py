@@ -14,7 +14,7 @@ from parity import assert_parity, compare_f32
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SPLIT_KERNELS = tuple("rsmp::fused_split_kernel<%d, %d>" % (ks, om) for ks in (7, 8, 9) for om in (0, 1, 2))
+SPLIT_KERNELS = tuple("rsmp::fused_split%s_kernel<%d, %d>" % (two, ks, om) for two in ("", "2") for ks in (7, 8, 9) for om in (0, 1, 2))
 
 
 def _plan_is_split_shaped(fi, fo, **kw):
@@ -34,7 +34,7 @@ def _kernels_of(r, x, chunk):
     (44100, 192000, 2, {"bandwidth": 99.0}),       # BASELINE configs[2]'s chain: 16384-point blocks, three sub-blocks
     (44100, 192000, 8, {"bandwidth": 99.0}),       # ... with its 8-channel frames (four pairs per frame, item_map)
     (44100, 192000, 6, {"bandwidth": 99.0}),
-    (44100, 192000, 2, {"bandwidth": 97.0}),       # 8192-point blocks: sub-blocks share one window and differ by their shift
+    (44100, 192000, 2, {"bandwidth": 97.0}),       # 8192-point blocks: one workgroup per block, polyphase stage in two rounds
     (44100, 192000, 4, {"bandwidth": 98.0}),       # ... with a longer filter (1425 taps)
     (22050, 96000, 2, {"bandwidth": 99.0}),
     # the polyphase stage LAST (float frames out): what a steep passband makes of the common conversions
@@ -55,6 +55,8 @@ def test_sub_blocked_chain_matches_the_oracle(fi, fo, nch, kw):
     r = F.Resampler(fi, fo, nch=nch, **kw)
     y, names = _kernels_of(r, x, 61000)
     assert names & set(SPLIT_KERNELS), names  # the path under test is the one that ran
+    if F.describe_plan(fi, fo, **kw)["stages"][0]["dft_length"] == 8192:  # ... in its whole-block, two-round form
+        assert any("fused_split2_kernel" in n for n in names), names
     assert "rsmp::seam_kernel" in names, names
     assert_parity(y, Oracle(fi, fo, nch, **kw).process(x, chunk=61000))
 
