@@ -82,7 +82,8 @@ constexpr int kSA = kFusedSA, kSB0 = kFusedSB0;
 // OUT64: the outputs go to the planar fp64 ring of the next stage's fifo (absolute index & mask: a ring wrap costs nothing)
 // instead of interleaved float frames -- chains like 44.1k->192k, whose x2 -> 80/147 pair feeds an x4 stage.
 //
-// SPLIT (LOG2P = 12; kernel name fused_split_kernel<KS, OMODE>): the sub-blocked form for x2 stages whose blocks (8192 or 16384 points) do not fit a workgroup.
+// SPLIT (LOG2P = 12; kernel names fused_split_kernel<KS, OMODE> / fused_split2_kernel<KS, OMODE>): the sub-blocked form for x2
+// stages whose blocks (8192 ... 32768 points) do not fit a workgroup.
 // A block of the reference is nsub workgroups; each computes `len` of the block's valid samples from a 4096-point window of
 // the block's inputs: y[2m + r] = IDFT_4096(DFT_4096(x) * G_r)[m], r = 0, 1 -- the block's two polyphase components, the same
 // linear convolution as the reference's one long transform, in a different fp64 summation order.  One forward and two inverse
