@@ -9,8 +9,12 @@ import foo_dsp_resampler_amd as F
 from oracle_binding import Oracle, lcg_noise
 from parity import compare_f32
 
-for fi, fo, nch, chunk, n_chunks in ((44100, 96000, 2, 4410, 3000), (96000, 44100, 6, 9600, 1000), (44100, 192000, 2, 4410, 800)):
-    r, o = F.Resampler(fi, fo, nch=nch), Oracle(fi, fo, nch)
+CASES = ((44100, 96000, 2, 4410, 3000, {}), (96000, 44100, 6, 9600, 1000, {}), (44100, 192000, 2, 4410, 800, {}),
+         # steep passbands: the sub-blocked kernels behind the host mirror (16384-point blocks; 8192-point blocks, two rounds)
+         (44100, 96000, 2, 4410, 1500, {"bandwidth": 99.0}), (44100, 48000, 4, 4410, 1000, {"bandwidth": 98.0}),
+         (44100, 192000, 2, 4410, 600, {"bandwidth": 99.0}))
+for fi, fo, nch, chunk, n_chunks, kw in CASES:
+    r, o = F.Resampler(fi, fo, nch=nch, **kw), Oracle(fi, fo, nch, **kw)
     worst, total, t0 = 0.0, 0, time.time()
     rng = np.random.RandomState(5)
     for k in range(n_chunks):
@@ -27,5 +31,5 @@ for fi, fo, nch, chunk, n_chunks in ((44100, 96000, 2, 4410, 3000), (96000, 4410
     r.drain(); o.drain()
     a, b = r.pull_all(), o.pull_all()
     assert a.shape == b.shape
-    print("%d->%d %dch: %d pushes, %d output frames, worst %.3f ulp, %.1f s" % (fi, fo, nch, n_chunks, total + a.shape[0], worst, time.time() - t0))
+    print("%d->%d %dch %r: %d pushes, %d output frames, worst %.3f ulp, %.1f s" % (fi, fo, nch, kw, n_chunks, total + a.shape[0], worst, time.time() - t0))
 print("soak ok")
