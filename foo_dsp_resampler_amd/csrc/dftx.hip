@@ -107,7 +107,10 @@ template <int DIR> __device__ __forceinline__ void fft8x(c64 (&u)[8], int tid, c
 // OKIND = 0 (generic): any block, element-wise fifo addressing where a span is split
 // (ring wrap, a block half in the ring and half in the caller's buffer, odd channel count) -- same arithmetic, so which
 // of the two a block gets changes no bit of its output.
-template <int LL, int OKIND> __global__ __launch_bounds__(256, 3) void dftx_kernel(AnyView in, AnyView out, DftArgs a)
+#ifndef RSMP_DFTX_WG // workgroups per CU the register budget is sized for (experiments: 2 = 256 VGPRs, 4 = 128)
+#define RSMP_DFTX_WG 3
+#endif
+template <int LL, int OKIND> __global__ __launch_bounds__(256, RSMP_DFTX_WG) void dftx_kernel(AnyView in, AnyView out, DftArgs a)
 {
   constexpr bool GENERIC = OKIND == 0;
   constexpr int P = kP, T8 = P / 8;
