@@ -2,7 +2,8 @@
 //
 // Run-time knobs (environment, read ONCE per process by knobs(); nothing on the launch path calls getenv).  Every one of
 // them only selects between kernel variants that produce the same samples to the parity bar, or sizes a buffer:
-//   RSMP_NO_FUSE / RSMP_NO_MFMA / RSMP_NO_POLYMF / RSMP_NO_FAST / RSMP_NO_DFTX / RSMP_NO_POLYI / RSMP_NO_POLYCOOP /
+//   RSMP_NO_FUSE / RSMP_NO_MFMA / RSMP_NO_POLYMF / RSMP_NO_FAST / RSMP_NO_SPLIT / RSMP_NO_SPLIT2 / RSMP_NO_DFTX / RSMP_NO_POLYI /
+//   RSMP_NO_POLYCOOP /
 //   RSMP_SPREAD_VECTOR    keep a chain off the named fast variant (the generic variant of the same stage runs instead)
 //   RSMP_NO_SIDE          seam kernels on the main stream instead of the side stream
 //   RSMP_NO_GRAPH         small pushes launch their kernels one by one instead of replaying a captured HIP graph

@@ -301,7 +301,7 @@ def test_many_launches_per_push(fo, nch, S, kw):
         "ys, ogs = [], []\n"
         "for _ in range(2):\n"
         "    y = torch.zeros((S, cap, nch), device='cuda'); torch.cuda.synchronize(); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
-        "launches = max(k['launches'] for k in r.profile_report() if 'fused' in k['kernel'] and 'prep' not in k['kernel'])\n"
+        "launches = max([k['launches'] for k in r.profile_report() if 'fused' in k['kernel'] and 'prep' not in k['kernel']] or [0])\n"
         "r.profile(False)\n"
         "for _ in range(2):\n"
         "    y = torch.zeros((S, cap, nch), device='cuda'); torch.cuda.synchronize(); iu, og = r.flow_device(x, n, y, cap); ys.append(y); ogs.append(og)\n"
@@ -316,4 +316,5 @@ def test_many_launches_per_push(fo, nch, S, kw):
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSMP_SEAM_RING_MB="4"), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-500:], p.stderr[-2000:])
     # at least three launches per push in the profiled pushes (main-stream seams) ... (two with the x4 stage's rings in the slab budget)
-    assert int(p.stdout.split()[1]) >= (6 if fo == 48000 else 4), p.stdout
+    if not (kw != "{}" and os.environ.get("RSMP_NO_SPLIT")):  # (with the sub-blocked kernel switched off these chains have no fused launch)
+        assert int(p.stdout.split()[1]) >= (6 if fo == 48000 else 4), p.stdout
