@@ -207,8 +207,8 @@ def check_against_oracle(cfg, x0, pushes, y_last):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[K] (default 1: the headline metric)")
     ap.add_argument("--streams", type=int, default=0, help="override: independent streams per GPU")
     ap.add_argument("--frames", type=int, default=0, help="override: frames per push (default: isamp_max, rate_base.h:531)")
