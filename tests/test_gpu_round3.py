@@ -110,7 +110,7 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 # ------------------------------------------------------------------------------------------------ bench shapes
-def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
+def _bench_shape_case(fi, fo, nch, S, kw, check_streams, expect_kernel=None):
     """bench.py's workload for one BASELINE config: S streams x isamp_max frames per push, device-resident in and out
     through RRX_flow_device, two steps (the second one starts from the first one's fifo state, slab cuts included), then a
     drain.  `check_streams` sample by sample against the oracle, every stream by frame count and a distinct checksum."""
@@ -122,12 +122,17 @@ def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     cap = int(n * fo / fi) + 65536  # a push's output varies by a block or two of the last stage around the mean
     ys, ogs = [], []
+    r.profile(True)
     for _ in range(2):
         y = dev_zeros((S, cap, nch))
         iu, og = r.flow_device(x, n, y, cap)
         assert iu == n
         ys.append(y)
         ogs.append(og)
+    names = {rec["kernel"] for rec in r.profile_report()}
+    r.profile(False)
+    if expect_kernel and not os.environ.get("RSMP_NO_SPLIT") and not os.environ.get("RSMP_NO_FAST"):
+        assert expect_kernel in names, names  # the kernel the bench line of this config is filed under is the one that ran
     r.drain()
     tail = dev_zeros((S, 16384, nch))
     og2 = r.pull_device(tail, 16384)
@@ -151,18 +156,18 @@ def _bench_shape_case(fi, fo, nch, S, kw, check_streams):
 
 def test_cfg2_bench_shape_against_oracle():
     """BASELINE configs[2]: 44.1k->192k, 8 ch, passband 99 % (16384-point dft -> vpoly0 -> x4 dft), 32 streams x 240 844 frames."""
-    _bench_shape_case(44100, 192000, 8, 32, {"bandwidth": 99.0}, (0, 17, 31))
+    _bench_shape_case(44100, 192000, 8, 32, {"bandwidth": 99.0}, (0, 17, 31), "rsmp::fused_split_kernel<9, 1>")
 
 
 def test_cfg3_bench_shape_against_oracle():
     """BASELINE configs[3]: 96k->44.1k, 32 ch, aliasing off, linear phase, 16 streams x 1 048 576 frames (item_map with 16
     pairs per frame)."""
-    _bench_shape_case(96000, 44100, 32, 16, {"allow_aliasing": 0, "phase": 50.0}, (0, 9, 15))
+    _bench_shape_case(96000, 44100, 32, 16, {"allow_aliasing": 0, "phase": 50.0}, (0, 9, 15), "rsmp::fused_fast_kernel<12, 8, false>")
 
 
 def test_cfg0_bench_shape_against_oracle():
     """BASELINE configs[0] as bench.py --config 0 runs it: 44.1k->48k stereo, 256 streams x 963 379 frames."""
-    _bench_shape_case(44100, 48000, 2, 256, {}, (0, 100, 255))
+    _bench_shape_case(44100, 48000, 2, 256, {}, (0, 100, 255), "rsmp::fused_fast_kernel<11, 8, false>")
 
 
 # ------------------------------------------------------------------------------------------------ RR_flow vs orc_flow (VERDICT r2 #5)
