@@ -5,8 +5,8 @@ whose entry points are what the reference plugin binds (rate/ratelib.h:72-81).  
 ctypes mirror of that interface used by the tests and bench.py; it contains no signal processing and
 no CPU fallback: if the library (or a GPU) is missing, calls fail.
 """
-from .ratelib import (RRConfig, RRError, Resampler, available_symbols, describe_plan, lib, lib_path,  # noqa: F401
+from .ratelib import (RRConfig, RRError, Resampler, available_symbols, describe_dispatch, describe_plan, lib, lib_path,  # noqa: F401
                       plan_table, RR_BEST, RR_NORM, EXPECTED_SYMBOLS)
 
-__all__ = ["RRConfig", "RRError", "Resampler", "describe_plan", "plan_table", "lib", "lib_path",
+__all__ = ["RRConfig", "RRError", "Resampler", "describe_plan", "describe_dispatch", "plan_table", "lib", "lib_path",
            "available_symbols", "RR_BEST", "RR_NORM", "EXPECTED_SYMBOLS"]

@@ -285,6 +285,38 @@ int RRX_describe_plan(const RR_config *config, char *buf, size_t cap)
   return int(n);
 }
 
+int RRX_describe_dispatch(const RR_config *config, int nchannels, char *buf, size_t cap)
+{
+  if (!config || !buf || !cap || nchannels < 1) return -RR_INVPARAM;
+  rsmp::ChainPlan plan;
+  int rc = rsmp::make_plan(to_config(config), plan);
+  if (rc) return -rc;
+  int nsub = 0, vs = 0;
+  const bool sub = !plan.stages.empty() && rsmp::split_geometry(plan, nchannels, 0, nsub, vs);
+  std::string s = "{\"sub_blocked\": ";
+  s += sub ? "true" : "false";
+  if (sub) {
+    const rsmp::DftFilter &f = plan.dft[plan.stages[0].filt];
+    const int V = f.N - (f.num_taps - 1), Pref = f.N / 2;
+    const bool two = nsub == 1 && vs > rsmp::kSplitVsMax;
+    char tmp[256];
+    snprintf(tmp, sizeof tmp, ", \"two_round\": %s, \"nsub\": %d, \"Vs\": %d, \"V\": %d, \"taps\": %d, \"N\": %d, \"Pref\": %d, \"sub_blocks\": [",
+             two ? "true" : "false", nsub, vs, V, f.num_taps, f.N, Pref);
+    s += tmp;
+    for (int i = 0; i < nsub; ++i) {
+      const rsmp::SubBlock sb = rsmp::sub_block(i, V, vs, Pref);
+      snprintf(tmp, sizeof tmp, "%s{\"off\": %d, \"len\": %d, \"win\": %d, \"shift\": %d}", i ? ", " : "", sb.off, sb.len, sb.win, sb.shift);
+      s += tmp;
+    }
+    s += "]";
+  }
+  s += "}";
+  size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+  std::memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  return int(n);
+}
+
 int RRX_plan_table(const RR_config *config, int which, double *out, size_t cap, size_t *count)
 {
   if (!config || which < 0 || which > 2) return RR_INVPARAM;

@@ -185,7 +185,9 @@ const double2 *Engine::twiddles8(int log2m)
 // so: sub-blocks per block and valid samples per sub-block.  The kernel has no generic form behind it, so everything it
 // needs is decided here, once, from the plan: x2 stage first in the chain (float frames in), even channel count, blocks of
 // 8192 ... 32768 points whose filter leaves >= 1024 valid samples in a pair of 4096-point component transforms, matrix-pipe tiles.
-bool Engine::split_geometry(int i, int &nsub, int &vs) const
+bool Engine::split_geometry(int i, int &nsub, int &vs) const { return rsmp::split_geometry(plan_, nch_, i, nsub, vs); }
+
+bool split_geometry(const ChainPlan &plan_, int nch_, int i, int &nsub, int &vs)
 {
   nsub = vs = 0;
   const Knobs &kn = knobs();

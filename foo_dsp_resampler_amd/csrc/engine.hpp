@@ -34,6 +34,10 @@ struct Book {
 // afterwards.  Every C-ABI entry that takes a handle runs under one (capi.cpp): a handle lives on the device it was opened
 // on, whatever device the calling thread has selected since (the plugin is ONE process whose converter threads each own
 // handles, chain.h:36; with RATELIB_AMD_DEVICES / RRX_open_batch_on those handles may sit on different GPUs).
+// Host-only (no device state): can dft stage i of `plan` and the polyphase stage behind it run as the sub-blocked fused kernel
+// for handles of `nch` channels per stream, and with what geometry (Engine::split_geometry; RRX_describe_dispatch)?
+bool split_geometry(const ChainPlan &plan, int nch, int i, int &nsub, int &vs);
+
 class DeviceScope {
 public:
   explicit DeviceScope(int device)

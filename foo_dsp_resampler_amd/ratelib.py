@@ -14,7 +14,7 @@ EXPECTED_SYMBOLS = [
     "init_ratelib", "close_ratelib", "RR_open", "RR_flow", "RR_push", "RR_pull", "RR_drain", "RR_close", "RR_strerror",
     "RRX_open_batch", "RRX_open_batch_on", "RRX_device", "RRX_push_device", "RRX_pull_device", "RRX_flow_device", "RRX_push_strided", "RRX_pull_strided",
     "RRX_set_stream", "RRX_sync", "RRX_profile", "RRX_profile_read", "RRX_profile_report", "RRX_debug_fail_alloc", "RRX_isamp_max", "RRX_available", "RRX_channels", "RRX_streams",
-    "RRX_describe_plan", "RRX_plan_table",
+    "RRX_describe_plan", "RRX_describe_dispatch", "RRX_plan_table",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
         L.RRX_channels.argtypes = [vp]
         L.RRX_streams.argtypes = [vp]
         L.RRX_describe_plan.argtypes = [P(RRConfig), C.c_char_p, sz]
+        L.RRX_describe_dispatch.argtypes = [P(RRConfig), C.c_int, C.c_char_p, sz]
         L.RRX_plan_table.argtypes = [P(RRConfig), C.c_int, vp, sz, P(sz)]
         _lib = L
     return _lib
@@ -138,6 +139,16 @@ def describe_plan(in_rate, out_rate, **kw):
     n = lib().RRX_describe_plan(C.byref(cfg), buf, len(buf))
     if n < 0:
         raise RRError(-n, "RRX_describe_plan")
+    return json.loads(buf.value.decode())
+
+
+def describe_dispatch(in_rate, out_rate, nch, **kw):
+    """Host-only: the kernel form of the first stage pair on `nch`-channel handles (dict; RRX_describe_dispatch).  Needs no GPU."""
+    cfg = _config(in_rate, out_rate, **kw)
+    buf = C.create_string_buffer(1 << 14)
+    n = lib().RRX_describe_dispatch(C.byref(cfg), int(nch), buf, len(buf))
+    if n < 0:
+        raise RRError(-n, "RRX_describe_dispatch")
     return json.loads(buf.value.decode())
 
 

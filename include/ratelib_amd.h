@@ -93,6 +93,14 @@ int RRX_streams(const RR_handle *h);
  * terminator), or the negated RR_error on failure; the text is truncated to cap-1 bytes. */
 int RRX_describe_plan(const RR_config *config, char *buf, size_t cap);
 
+/* Host-only (no GPU needed): which kernel form the first stage pair of `config` gets on handles of `nchannels` channels per
+ * stream, as JSON: {"sub_blocked": false} or {"sub_blocked": true, "two_round": .., "nsub": .., "Vs": .., "V": .., "taps": ..,
+ * "N": .., "Pref": .., "sub_blocks": [{"off", "len", "win", "shift"} ...]} -- the geometry of the sub-blocked fused kernels
+ * (DESIGN.md 4), decided from the plan alone.  Nothing in the reference corresponds to it (its blocks are one transform
+ * each, rate/dft_filter.h:60-190); it exists so that the decision can be tested without a device.  Returns as
+ * RRX_describe_plan does. */
+int RRX_describe_dispatch(const RR_config *config, int nchannels, char *buf, size_t cap);
+
 /* Host-only: copy a designed table for `config` into out[0..cap): which = 0 / 1 -> taps of the first /
  * second DFT-stage filter (after phase conversion, before the 2L/N scaling of rate_base.h:175),
  * which = 2 -> polyphase table [phase][tap][order+1] (rate/prepare_coefs.h:20-46).  *count receives

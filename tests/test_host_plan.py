@@ -271,3 +271,51 @@ def test_environment_is_read_once():
                     hits.append((os.path.basename(path), n))
     assert {f for f, _ in hits} <= {"engine.cpp", "capi.cpp"}, hits
     assert len([1 for f, _ in hits if f == "capi.cpp"]) == 1, hits
+
+
+# ------------------------------------------------------------------------------------------------ sub-blocked dispatch (host side)
+_SPLIT_RATES = [(44100, 48000), (44100, 96000), (44100, 192000), (48000, 44100), (22050, 64000), (8000, 44100), (11025, 64000),
+                (44100, 88200), (96000, 44100), (32000, 44100), (44100, 64000), (16000, 88200)]
+
+
+@pytest.mark.parametrize("bw", [90.0, 95.0, 97.0, 98.0, 99.0, 99.5, 99.7])
+def test_sub_blocked_geometry_covers_each_block_exactly_and_stays_valid(bw):
+    """RRX_describe_dispatch (host-only): for every chain the sub-blocked fused kernels would take, the sub-blocks tile the
+    block's V valid samples without gap or overlap, have even lengths, read only inputs of the block's own span, and every
+    sample lies where the two 4096-point component transforms are free of wrap-around (2 shift + len + taps - 1 <= 8192).
+    The whole-block two-round form is chosen exactly for 8192-point blocks; chains the kernels do not cover are left alone."""
+    seen = {"sub": 0, "two": 0, "plain": 0}
+    for fi, fo in _SPLIT_RATES:
+        st = F.describe_plan(fi, fo, bandwidth=bw)["stages"]
+        for nch in (1, 2, 3, 6, 8):
+            d = F.describe_dispatch(fi, fo, nch, bandwidth=bw)
+            shaped = (len(st) >= 2 and st[0]["kind"] == "dft" and st[0]["L"] == 2 and st[0]["dft_length"] in (8192, 16384, 32768)
+                      and st[1]["kind"] == "poly" and st[1]["interp_order"] == 0 and st[1]["L"] >= 64)
+            if not d["sub_blocked"]:
+                seen["plain"] += 1
+                assert not (shaped and nch % 2 == 0), (fi, fo, bw, nch, st[0])  # every chain of this shape with an even channel count is covered
+                continue
+            assert shaped and nch % 2 == 0, (fi, fo, bw, nch)
+            V, taps, N, Pref = d["V"], d["taps"], d["N"], d["Pref"]
+            assert N == st[0]["dft_length"] and taps == st[0]["num_taps"] and V == N - (taps - 1) and Pref == N // 2
+            sbs = d["sub_blocks"]
+            assert len(sbs) == d["nsub"] >= 1
+            pos = 0
+            for sb in sbs:
+                assert sb["off"] == pos and sb["len"] > 0 and sb["len"] % 2 == 0 and sb["off"] % 2 == 0
+                assert 0 <= sb["win"] <= Pref - 4096 and sb["shift"] == sb["off"] // 2 - sb["win"] >= 0
+                assert 2 * sb["shift"] + sb["len"] + (taps - 1) <= 8192, (fi, fo, bw, sb)
+                pos += sb["len"]
+            assert pos == V
+            if d["two_round"]:
+                seen["two"] += 1
+                assert N == 8192 and d["nsub"] == 1 and d["Vs"] == V > 5056
+            else:
+                seen["sub"] += 1
+                assert d["Vs"] <= 5056 and all(sb["len"] <= d["Vs"] for sb in sbs)
+    if bw in (97.0, 98.0):
+        assert seen["two"] > 0, seen
+    if bw in (99.0, 99.5):
+        assert seen["sub"] > 0, seen
+    if bw in (90.0, 95.0, 99.7):
+        assert seen["sub"] == seen["two"] == 0, seen  # 4096-point blocks are the lean kernel's; 65536-point ones stay four-step
